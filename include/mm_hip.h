@@ -1,0 +1,148 @@
+/*
+ * mm_hip.h - C ABI of libmm_hip.so: the MI355X (gfx950) hot path of the NeoX/MAGMA
+ * ParallelTransformerLayer (reference: megatron/model/transformer.py:644-801).
+ *
+ * Conventions (every entry point):
+ *   - plain device pointers + sizes; no torch types; caller owns every buffer;
+ *   - nothing is allocated and nothing synchronises inside (graph-capture safe) unless stated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - `dtype`: MM_BF16 or MM_F16 (the reference's fused kernels accept exactly Half/BFloat16,
+ *     megatron/fused_kernels/scaled_masked_softmax.cpp:34-37); fp32 accumulation everywhere;
+ *   - return 0 on success, a negative MM_E* code otherwise; mm_last_error() gives the text
+ *     (the Python shim raises RuntimeError, matching the reference's AT_ASSERTM behaviour).
+ */
+#ifndef MM_HIP_H
+#define MM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MM_BF16 = 0, MM_F16 = 1 };
+enum { MM_OK = 0, MM_EINVAL = -1, MM_EUNSUPPORTED = -2, MM_ELAUNCH = -3 };
+
+const char* mm_last_error(void);
+/* Library/arch identification: returns "gfx950". */
+const char* mm_target_arch(void);
+
+/* ------------------------------------------------------------------ fused softmax
+ * Replaces scaled_upper_triang_masked_softmax_cuda.{forward,backward}
+ *   (megatron/fused_kernels/scaled_upper_triang_masked_softmax.cpp:31-70,
+ *    kernels scaled_upper_triang_masked_softmax.h:143-361).
+ * in/out: [attn_batches, s, s] contiguous; row r gets softmax(scale * x[r, 0..r]), zeros for cols > r.
+ * s <= 2048 (reference: _cuda.cu:36).  bwd writes IN PLACE into grad_inout (reference: _cuda.cu:77-87). */
+int mm_softmax_causal_fwd(void* out, const void* in, float scale, int attn_batches, int s,
+                          int dtype, void* stream);
+int mm_softmax_causal_bwd(void* grad_inout, const void* softmax_out, float scale, int attn_batches,
+                          int s, int dtype, void* stream);
+
+/* Replaces scaled_masked_softmax_cuda.{forward,backward,get_batch_per_block}
+ *   (megatron/fused_kernels/scaled_masked_softmax.cpp:33-83, kernels scaled_masked_softmax.h:117-352).
+ * in/out: [b, np, sq, sk]; mask: uint8 [pad_batches, 1, sq, sk], pad_batches in {1, b}, value 1 = masked
+ * (filled with -10000 before the max, .h:180-184).  sk <= 2048. */
+int mm_softmax_masked_fwd(void* out, const void* in, const uint8_t* mask, float scale, int b, int np,
+                          int sq, int sk, int pad_batches, int dtype, void* stream);
+int mm_softmax_masked_bwd(void* grad_inout, const void* softmax_out, float scale, int b, int np, int sq,
+                          int sk, int dtype, void* stream);
+/* Same integer the reference computes with C10_WARP_SIZE = 64 on ROCm (scaled_masked_softmax.h:338-352);
+ * fused_softmax.py:160-167 uses it for eligibility. Host-only. */
+int mm_softmax_batch_per_block(int sq, int sk, int b, int np);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * Replaces torch.nn.LayerNorm as used at megatron/model/transformer.py:669,696,737,776,791
+ * (megatron/model/norms.py:16-31).  x,y: [rows, h]; w,b: [h] in `dtype`; mean/rstd: [rows] fp32 (saved for bwd).
+ * `y2/w2/b2` optional (NULL): second affine output from the same statistics - the GPT-J residual
+ * variant normalises the same x twice (transformer.py:737). */
+int mm_layernorm_fwd(void* y, void* y2, float* mean, float* rstd, const void* x, const void* w,
+                     const void* b, const void* w2, const void* b2, int rows, int h, float eps,
+                     int dtype, void* stream);
+/* dx = LN'(dy; w) [+ LN'(dy2; w2)] [+ dresidual].  dwdb_partial: fp32 [nblk, 2 or 4, h] scratch, or NULL to skip
+ * parameter grads (frozen LM).  nblk = mm_layernorm_bwd_nblk(rows).  Finalize with mm_layernorm_bwd_finalize. */
+int mm_layernorm_bwd_nblk(int rows);
+int mm_layernorm_bwd(void* dx, float* dwdb_partial, const void* dy, const void* dy2,
+                     const void* dresidual, const void* x, const void* w, const void* w2,
+                     const float* mean, const float* rstd, int rows, int h, int dtype, void* stream);
+/* out_k[h] (dtype) = sum over nblk of partial[:, k, :], k = 0..nvec-1; outs[k] may be NULL. */
+int mm_layernorm_bwd_finalize(void* const* outs, const float* dwdb_partial, int nblk, int nvec, int h,
+                              int dtype, void* stream);
+
+/* ------------------------------------------------------------------ rotary
+ * Replaces apply_rotary_pos_emb{,_torch} + the slicing/cat around it
+ * (megatron/model/positional_embeddings.py:69-92, transformer.py:566-596), IN PLACE on the fused
+ * QKV activation [s, b, np, 3*hn]: q = [..., 0:hn], k = [..., hn:2hn] (transformer.py:555-564).
+ * cos/sin: [>= offset+s, d] tables in `dtype` (built the reference's way by the caller).
+ * Rounds each product and the sum to `dtype` like the eager reference.  inverse != 0 applies the
+ * transposed rotation (backward). */
+int mm_rotary_qk_inplace(void* qkv, const void* cos, const void* sin, int s, int b, int np, int hn,
+                         int d, int offset, int inverse, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ bias-GeLU / bias-dropout-add
+ * Replaces bias_gelu / bias_gelu_back (megatron/model/activations.py:62-96) [mode 0, tanh] and
+ * F.gelu(x + bias) (transformer.py:127-130) [mode 1, erf].  y: [rows, cols], bias: [cols]. */
+int mm_bias_gelu_fwd(void* out, const void* y, const void* bias, int rows, int cols, int mode,
+                     int dtype, void* stream);
+/* dy = g * gelu'(y + bias), may alias g. */
+int mm_bias_gelu_bwd(void* dy, const void* g, const void* y, const void* bias, int rows, int cols,
+                     int mode, int dtype, void* stream);
+/* Replaces bias_dropout_add (megatron/model/fused_bias_dropout.py:28-55):
+ * out = residual + dropout(x + bias); bias [cols] or NULL, residual [rows, cols] or NULL.
+ * p > 0 in training draws a Philox4x32-10 keep mask from (seed, offset) and (optionally) stores it as
+ * uint8 in keep_mask (NULL to skip). */
+int mm_bias_dropout_add(void* out, const void* x, const void* bias, const void* residual,
+                        uint8_t* keep_mask, int rows, int cols, float p, int training,
+                        uint64_t seed, uint64_t offset, int dtype, void* stream);
+/* Column sums: out[cols] (dtype) = sum_rows x[rows, cols] (bias gradients). partial: fp32 [mm_colsum_nblk(rows), cols]. */
+int mm_colsum_nblk(int rows);
+int mm_colsum(void* out, float* partial, const void* x, int rows, int cols, int dtype, void* stream);
+/* out[c, r] = in[r, c] (2-byte elements). */
+int mm_transpose2d(void* out, const void* in, int rows, int cols, void* stream);
+/* elementwise out = a + b (+ c), n elements. */
+int mm_add(void* out, const void* a, const void* b, const void* c, size_t n, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ GEMM (MFMA)
+ * Replaces F.linear in ColumnParallelLinear / RowParallelLinear (megatron/mpu/layers.py:557,745):
+ *   C[M, N] = A[M, K] * B[N, K]^T  (+ bias[N]) (+ epilogue), fp32 accumulate, output in `dtype`.
+ * A, B row-major with leading dimensions lda, ldb (elements); C row-major ldc.
+ * epilogue: MM_EPI_NONE | MM_EPI_BIAS | MM_EPI_BIAS_GELU_TANH | MM_EPI_BIAS_GELU_ERF (aux [M, N], ld = ldc,
+ *           receives the rounded pre-bias product that the reference's GeLU backward re-reads; C the activation)
+ *           | MM_EPI_BIAS_RELU (adapter, megatron/model/adapter.py:18-24).
+ * Requirements: K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned A/B, 8-byte aligned C/aux/bias. */
+enum {
+    MM_EPI_NONE = 0,
+    MM_EPI_BIAS = 1,
+    MM_EPI_BIAS_GELU_TANH = 2,
+    MM_EPI_BIAS_GELU_ERF = 3,
+    MM_EPI_BIAS_RELU = 4
+};
+/* residual (optional, [M, N] with leading dimension ldc, may alias C): C = round(epilogue(...)) + residual. */
+int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual,
+               int M, int N, int K, int lda, int ldb, int ldc, int epilogue, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ fused attention
+ * Replaces ParallelSelfAttention.attention + the permute after it
+ * (megatron/model/transformer.py:315-416, 623-630) without materialising [b*np, s, s].
+ * qkv: [s, b, np, 3*hn] (the QKV linear's output, after rotary); ctx: [s, b, np*hn];
+ * lse: [b, np, s] fp32 (log-sum-exp of scaled scores, saved for bwd).
+ * mask_mode 0: implicit causal (-inf above the diagonal: scaled_upper_triang semantics);
+ * mask_mode 1: explicit uint8 mask [mask_batches(1|b), 1, s, s], 1 = masked, filled with -10000
+ *              (scaled_masked_softmax / eager gpt2_attention_mask_func semantics).
+ * softmax_scale multiplies q.k (reference: 1/norm_factor, transformer.py:351).  hn in {64, 128}. */
+int mm_attn_fwd(void* ctx, float* lse, const void* qkv, const uint8_t* mask, int mask_mode,
+                int mask_batches, int s, int b, int np, int hn, float softmax_scale, int dtype,
+                void* stream);
+/* dqkv: [s, b, np, 3*hn] gradient wrt the (post-rotary) qkv; delta: [b, np, s] fp32 scratch. */
+int mm_attn_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse,
+                const void* qkv, const uint8_t* mask, int mask_mode, int mask_batches, int s, int b,
+                int np, int hn, float softmax_scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ test-only hardware probe
+ * One wave reads a [16][64] 16-bit LDS tile with ds_read_b64_tr_b16; out: [64 lanes][4].  No reference counterpart. */
+int mm_debug_probe_tr_read(void* out, const void* in, const int* row0, const int* col0, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM_HIP_H */

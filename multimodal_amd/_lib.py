@@ -1,0 +1,79 @@
+"""ctypes binding of ``libmm_hip.so`` (the C ABI declared in ``include/mm_hip.h``).
+
+The library is the product: there is NO fallback.  If it is missing, or a call returns an
+error code, a ``RuntimeError`` is raised (the reference's pybind modules raise ``RuntimeError``
+through ``AT_ASSERTM`` the same way, megatron/fused_kernels/scaled_masked_softmax.cpp:34-37).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmm_hip.so")
+
+MM_BF16, MM_F16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GELU_ERF, EPI_BIAS_RELU = 0, 1, 2, 3, 4
+
+c_int, c_float, c_void_p, c_size_t, c_u64 = (
+    ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64)
+
+# name -> (restype, argtypes); must list every symbol include/mm_hip.h declares
+# (tests/test_abi.py cross-checks this table against the header).
+PROTOTYPES = {
+    "mm_last_error": (ctypes.c_char_p, []),
+    "mm_target_arch": (ctypes.c_char_p, []),
+    "mm_softmax_causal_fwd": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+    "mm_softmax_causal_bwd": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+    "mm_softmax_masked_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mm_softmax_masked_bwd": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mm_softmax_batch_per_block": (c_int, [c_int, c_int, c_int, c_int]),
+    "mm_layernorm_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_float, c_int, c_void_p]),
+    "mm_layernorm_bwd_nblk": (c_int, [c_int]),
+    "mm_layernorm_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p]),
+    "mm_layernorm_bwd_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mm_rotary_qk_inplace": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "mm_bias_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mm_bias_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mm_bias_dropout_add": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_int, c_u64, c_u64, c_int, c_void_p]),
+    "mm_colsum_nblk": (c_int, [c_int]),
+    "mm_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mm_transpose2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mm_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "mm_gemm_nt": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
+    "mm_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "mm_attn_bwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
+    "mm_debug_probe_tr_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def get_lib():
+    """Load libmm_hip.so once; raise loudly if it is not built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C multimodal_amd/csrc`). multimodal_amd has no fallback path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = get_lib().mm_last_error().decode(errors="replace")
+        raise RuntimeError(f"multimodal_amd: {what or 'call'} failed (code {rc}): {msg}")
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.bfloat16:
+        return MM_BF16
+    if torch_dtype == torch.float16:
+        return MM_F16
+    raise RuntimeError(f"multimodal_amd: only fp16 and bf16 are supported on the HIP path, got {torch_dtype}")

@@ -1,0 +1,103 @@
+// common.h - shared device helpers for the gfx950 kernels (wave64, 16-byte vector access).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mm_hip.h"
+
+namespace mm {
+
+void set_error(const char* fmt, ...);
+
+#define MM_CHECK_ARG(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            mm::set_error(__VA_ARGS__);    \
+            return (int)MM_EINVAL;             \
+        }                                  \
+    } while (0)
+
+#define MM_CHECK_LAUNCH()                                                  \
+    do {                                                                   \
+        hipError_t e__ = hipGetLastError();                                \
+        if (e__ != hipSuccess) {                                           \
+            mm::set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return (int)MM_ELAUNCH;                                            \
+        }                                                                  \
+    } while (0)
+
+constexpr int kWave = 64;
+
+typedef uint16_t u16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// ---- 16-bit <-> fp32 conversions.  T tag: 0 = bf16, 1 = f16.
+struct BF16 {};
+struct F16 {};
+
+template <typename T> __device__ __forceinline__ float to_f32(u16 v);
+template <> __device__ __forceinline__ float to_f32<BF16>(u16 v) { return __uint_as_float(((uint32_t)v) << 16); }
+template <> __device__ __forceinline__ float to_f32<F16>(u16 v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return (float)h;
+}
+template <typename T> __device__ __forceinline__ u16 from_f32(float f);
+template <> __device__ __forceinline__ u16 from_f32<BF16>(float f) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+    __bf16 h = (__bf16)f;
+    u16 r;
+    __builtin_memcpy(&r, &h, 2);
+    return r;
+}
+template <> __device__ __forceinline__ u16 from_f32<F16>(float f) {
+    _Float16 h = (_Float16)f;
+    u16 r;
+    __builtin_memcpy(&r, &h, 2);
+    return r;
+}
+// round-trip through the 16-bit type (mimics an eager elementwise op's output rounding)
+template <typename T> __device__ __forceinline__ float rnd(float f) { return to_f32<T>(from_f32<T>(f)); }
+
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = to_f32<T>((u16)(v[i] & 0xffffu));
+        f[2 * i + 1] = to_f32<T>((u16)(v[i] >> 16));
+    }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (uint32_t)from_f32<T>(f[2 * i]) | ((uint32_t)from_f32<T>(f[2 * i + 1]) << 16);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename F> inline int dispatch_dtype(int dtype, F&& f) {
+    if (dtype == MM_BF16) return f(BF16{});
+    if (dtype == MM_F16) return f(F16{});
+    set_error("unsupported dtype code %d (only MM_BF16, MM_F16)", dtype);
+    return MM_EUNSUPPORTED;
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace mm

@@ -1,0 +1,28 @@
+// debug.hip - hardware-semantics probes used only by tests (tests/test_hw_probes.py).
+#include "common.h"
+
+namespace mm {
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// One wave.  tile: [rows=16][cols=64] of 16-bit values in LDS.  Lane (g = lane>>4, i = lane&15, q = i>>2, p = i&3)
+// supplies the address of element [row0(g) + q][col0(g) + 4p] and receives 4 values.
+__global__ void probe_tr_read_k(short* __restrict__ out, const short* __restrict__ in, const int* __restrict__ row0,
+                                const int* __restrict__ col0) {
+    __shared__ __attribute__((aligned(16))) short tile[16 * 64];
+    for (int i = threadIdx.x; i < 16 * 64; i += 64) tile[i] = in[i];
+    __syncthreads();
+    const int lane = threadIdx.x, g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const short* addr = &tile[(row0[g] + q) * 64 + col0[g] + 4 * p];
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)addr);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[lane * 4 + j] = v[j];
+}
+}  // namespace mm
+
+extern "C" int mm_debug_probe_tr_read(void* out, const void* in, const int* row0, const int* col0, void* stream) {
+    MM_CHECK_ARG(out && in && row0 && col0, "mm_debug_probe_tr_read: null pointer");
+    mm::probe_tr_read_k<<<1, 64, 0, (hipStream_t)stream>>>((short*)out, (const short*)in, row0, col0);
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}

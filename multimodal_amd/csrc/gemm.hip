@@ -1,0 +1,229 @@
+// gemm.hip - bf16/f16 MFMA GEMM  C[M,N] = A[M,K] * B[N,K]^T  with fused epilogues (gfx950).
+//
+// Replaces F.linear inside ColumnParallelLinear / RowParallelLinear
+// (reference megatron/mpu/layers.py:557,745) and the adapter's nn.Linear (megatron/model/adapter.py:18-24).
+//
+// Structure (v1, "128x128x64, one barrier per K-tile"):
+//   * 256 threads = 4 waves, wave (wr, wc) owns a 64x64 sub-tile as 4x4 MFMA 16x16x32 accumulators;
+//   * A and B K-tiles are staged global -> LDS by global_load_lds (16 B per lane, no VGPR round trip),
+//     double-buffered: tile t+1 is in flight while tile t feeds the MFMAs;
+//   * LDS image is lane-linear per wave-instruction (8 rows x 128 B); bank conflicts of the ds_read_b128
+//     fragment reads are removed by XOR-swizzling the 16-byte chunk index with (row>>1)&7 on the
+//     SOURCE address and on the READ address (both sides or neither);
+//   * operands are swapped (MFMA A-operand = B tile) so that each lane ends up with 4 consecutive
+//     output columns of one row -> 8-byte epilogue stores and 8-byte bias loads;
+//   * blockIdx is remapped so that the blocks of one XCD (blockIdx % 8) walk neighbouring tiles
+//     (shared A row-panels / B column-panels stay in that XCD's L2).
+#include "common.h"
+
+namespace mm {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename T> struct Mfma;
+template <> struct Mfma<BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float gelu_tanh_dev(float x) {
+    return x * 0.5f * (1.0f + tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x)));
+}
+__device__ __forceinline__ float gelu_erf_dev(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// stage one 128x64 tile (rows row0.., k-offset k0) of X (ld elements per row, nrows valid rows) into lds_tile
+template <typename T>
+__device__ __forceinline__ void stage_tile(char* lds_tile, const u16* __restrict__ X, int ld, int row0, int nrows, int k0,
+                                           int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + (lane >> 3);      // row inside the tile
+        const int cl = lane & 7;                            // chunk position in LDS
+        const int cg = cl ^ ((r >> 1) & 7);                 // global chunk that belongs there
+        int gr = row0 + r;
+        gr = gr < nrows ? gr : nrows - 1;                   // clamp: edge tiles re-read the last row (never stored)
+        const u16* src = X + (size_t)gr * ld + k0 + cg * 8;
+        char* dst = lds_tile + (wave * 32 + i * 8) * (BK * 2);  // wave-uniform; HW adds lane*16
+        __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+}
+
+template <typename T, int EPI, bool RES>
+__global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ A,
+                                                     const u16* __restrict__ B, const u16* __restrict__ bias,
+                                                     const u16* __restrict__ Rsd, int M, int N, int K, int lda, int ldb,
+                                                     int ldc, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    // ---- XCD-aware tile mapping (bijective for any grid size), then grouped ordering (8 tile-rows per group)
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int group_sz = GROUP_M * tiles_n;
+    const int group = bid / group_sz;
+    const int first_m = group * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (bid % group_sz) % gm;
+    const int tn = (bid % group_sz) / gm;
+    const int bm = tm * BM, bn = tn * BN;
+
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = K / BK;
+    // stage s: A tile at smem + s*2*TILE_BYTES, B tile right behind it
+    stage_tile<T>(smem, A, lda, bm, M, 0, wave, lane);
+    stage_tile<T>(smem + TILE_BYTES, B, ldb, bn, N, 0, wave, lane);
+    __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
+
+    // per-lane fragment read offsets (bytes) inside a tile, for kk = 0; kk = 1 flips chunk bit 2
+    const int frow = lane & 15, fq = lane >> 4;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + i * 16 + frow;
+        const int rb = wc * 64 + i * 16 + frow;
+        offA[i] = ra * (BK * 2) + ((fq ^ ((ra >> 1) & 7)) << 4);
+        offB[i] = rb * (BK * 2) + ((fq ^ ((rb >> 1) & 7)) << 4);
+    }
+
+    typedef typename Mfma<T>::frag frag;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            char* nxt = smem + (cur ^ 1) * (2 * TILE_BYTES);
+            stage_tile<T>(nxt, A, lda, bm, M, (t + 1) * BK, wave, lane);
+            stage_tile<T>(nxt + TILE_BYTES, B, ldb, bn, N, (t + 1) * BK, wave, lane);
+        }
+        const char* a_base = smem + cur * (2 * TILE_BYTES);
+        const char* b_base = a_base + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            frag fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const frag*>(a_base + (offA[i] ^ (kk << 6)));
+                fb[i] = *reinterpret_cast<const frag*>(b_base + (offB[i] ^ (kk << 6)));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mfma<T>::run(fb[ni], fa[mi], acc[ni][mi]);
+        }
+        __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+    }
+
+    // ---- epilogue: lane holds C[m][n0..n0+3], m = bm + wr*64 + mi*16 + frow, n0 = bn + wc*64 + ni*16 + fq*4
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n0 = bn + wc * 64 + ni * 16 + fq * 4;
+        if (n0 >= N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (EPI != MM_EPI_NONE) {
+            const u32x2 braw = *reinterpret_cast<const u32x2*>(bias + n0);
+            bv[0] = to_f32<T>((u16)(braw[0] & 0xffffu)); bv[1] = to_f32<T>((u16)(braw[0] >> 16));
+            bv[2] = to_f32<T>((u16)(braw[1] & 0xffffu)); bv[3] = to_f32<T>((u16)(braw[1] >> 16));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = bm + wr * 64 + mi * 16 + frow;
+            if (m >= M) continue;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = acc[ni][mi][j];
+            const size_t off = (size_t)m * ldc + n0;
+            if (EPI == MM_EPI_BIAS_GELU_TANH || EPI == MM_EPI_BIAS_GELU_ERF) {
+                u16 u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = from_f32<T>(o[j]);
+                *reinterpret_cast<u32x2*>(aux + off) = u32x2{(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = to_f32<T>(u[j]) + bv[j];
+                    o[j] = (EPI == MM_EPI_BIAS_GELU_TANH) ? gelu_tanh_dev(x) : gelu_erf_dev(rnd<T>(x));
+                }
+            } else if (EPI == MM_EPI_BIAS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += bv[j];
+            } else if (EPI == MM_EPI_BIAS_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaxf(rnd<T>(o[j] + bv[j]), 0.f);
+            }
+            if (RES) {
+                const u32x2 rr = *reinterpret_cast<const u32x2*>(Rsd + off);
+                o[0] = rnd<T>(o[0]) + to_f32<T>((u16)(rr[0] & 0xffffu)); o[1] = rnd<T>(o[1]) + to_f32<T>((u16)(rr[0] >> 16));
+                o[2] = rnd<T>(o[2]) + to_f32<T>((u16)(rr[1] & 0xffffu)); o[3] = rnd<T>(o[3]) + to_f32<T>((u16)(rr[1] >> 16));
+            }
+            *reinterpret_cast<u32x2*>(C + off) =
+                u32x2{(uint32_t)from_f32<T>(o[0]) | ((uint32_t)from_f32<T>(o[1]) << 16),
+                      (uint32_t)from_f32<T>(o[2]) | ((uint32_t)from_f32<T>(o[3]) << 16)};
+        }
+    }
+}
+
+template <typename T, int EPI>
+static int launch_gemm(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N,
+                       int K, int lda, int ldb, int ldc, hipStream_t st) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n), block(256);
+    if (residual)
+        gemm_nt_128_k<T, EPI, true><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
+                                                            (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n);
+    else
+        gemm_nt_128_k<T, EPI, false><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
+                                                             nullptr, M, N, K, lda, ldb, ldc, tiles_m, tiles_n);
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M,
+                          int N, int K, int lda, int ldb, int ldc, int epilogue, int dtype, void* stream) {
+    MM_CHECK_ARG(C && A && B, "mm_gemm_nt: null pointer");
+    MM_CHECK_ARG(M > 0 && N > 0 && K > 0, "mm_gemm_nt: M=%d N=%d K=%d must be positive", M, N, K);
+    MM_CHECK_ARG(K % 64 == 0, "mm_gemm_nt: K=%d must be a multiple of 64", K);
+    MM_CHECK_ARG(N % 4 == 0, "mm_gemm_nt: N=%d must be a multiple of 4", N);
+    MM_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "mm_gemm_nt: leading dimensions too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    MM_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "mm_gemm_nt: lda/ldb must be multiples of 8 and ldc of 4");
+    MM_CHECK_ARG(aligned16(A) && aligned16(B), "mm_gemm_nt: A and B must be 16-byte aligned");
+    MM_CHECK_ARG((((uintptr_t)C) & 7) == 0, "mm_gemm_nt: C must be 8-byte aligned");
+    MM_CHECK_ARG(epilogue >= MM_EPI_NONE && epilogue <= MM_EPI_BIAS_RELU, "mm_gemm_nt: unknown epilogue %d", epilogue);
+    if (epilogue != MM_EPI_NONE) MM_CHECK_ARG(bias && (((uintptr_t)bias) & 7) == 0, "mm_gemm_nt: epilogue %d needs an 8-byte aligned bias", epilogue);
+    if (epilogue == MM_EPI_BIAS_GELU_TANH || epilogue == MM_EPI_BIAS_GELU_ERF)
+        MM_CHECK_ARG(aux && (((uintptr_t)aux) & 7) == 0, "mm_gemm_nt: GeLU epilogues need an 8-byte aligned aux buffer");
+    if (residual) MM_CHECK_ARG((((uintptr_t)residual) & 7) == 0, "mm_gemm_nt: residual must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        switch (epilogue) {
+            case MM_EPI_NONE: return launch_gemm<T, MM_EPI_NONE>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+            case MM_EPI_BIAS: return launch_gemm<T, MM_EPI_BIAS>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+            case MM_EPI_BIAS_GELU_TANH: return launch_gemm<T, MM_EPI_BIAS_GELU_TANH>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+            case MM_EPI_BIAS_GELU_ERF: return launch_gemm<T, MM_EPI_BIAS_GELU_ERF>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+            default: return launch_gemm<T, MM_EPI_BIAS_RELU>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+        }
+    });
+}

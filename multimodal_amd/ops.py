@@ -1,0 +1,283 @@
+"""Tensor-level wrappers over the C ABI (``include/mm_hip.h``).
+
+torch is used here for device memory and the current HIP stream only; every computation is a
+hand-written gfx950 kernel in ``libmm_hip.so``.  All functions require CUDA(HIP) tensors and raise
+``RuntimeError`` on misuse.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, dtype_code, get_lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("multimodal_amd: tensors must live on the GPU (the HIP path has no CPU fallback)")
+
+
+# ---------------------------------------------------------------------------- softmax
+def softmax_causal_fwd(x, scale):
+    """[attn_batches, s, s] -> softmax(scale*x) under the implicit causal mask (allocates the output,
+    like scaled_upper_triang_masked_softmax_cuda.forward, *_cuda.cu:52-54)."""
+    _need_cuda(x)
+    if x.dim() != 3 or x.size(1) != x.size(2):
+        raise RuntimeError("expected 3D tensor [attn_batches, s, s]")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(get_lib().mm_softmax_causal_fwd(out.data_ptr(), x.data_ptr(), float(scale), x.size(0), x.size(1),
+                                          dtype_code(x.dtype), _stream()), "softmax_causal_fwd")
+    return out
+
+
+def softmax_causal_bwd(grad, y, scale):
+    """In place into ``grad`` (a contiguous copy is made first if needed, as the reference does)."""
+    _need_cuda(grad, y)
+    if grad.dim() != 3 or y.shape != grad.shape:
+        raise RuntimeError("expected matching 3D tensors")
+    grad = grad.contiguous()
+    y = y.contiguous()
+    check(get_lib().mm_softmax_causal_bwd(grad.data_ptr(), y.data_ptr(), float(scale), grad.size(0), grad.size(1),
+                                          dtype_code(grad.dtype), _stream()), "softmax_causal_bwd")
+    return grad
+
+
+def softmax_masked_fwd(x, mask, scale):
+    _need_cuda(x, mask)
+    if x.dim() != 4 or mask.dim() != 4:
+        raise RuntimeError("expected 4D input and mask")
+    b, np_, sq, sk = x.shape
+    if mask.size(1) != 1 or mask.size(2) != sq or mask.size(3) != sk or mask.size(0) not in (1, b):
+        raise RuntimeError(f"mask shape {tuple(mask.shape)} does not match input {tuple(x.shape)}")
+    x = x.contiguous()
+    m = mask.contiguous()
+    if m.dtype == torch.bool:
+        m = m.view(torch.uint8)
+    elif m.dtype != torch.uint8:
+        m = m.to(torch.uint8)
+    out = torch.empty_like(x)
+    check(get_lib().mm_softmax_masked_fwd(out.data_ptr(), x.data_ptr(), m.data_ptr(), float(scale), b, np_, sq, sk,
+                                          m.size(0), dtype_code(x.dtype), _stream()), "softmax_masked_fwd")
+    return out
+
+
+def softmax_masked_bwd(grad, y, scale):
+    _need_cuda(grad, y)
+    if grad.dim() != 4 or y.shape != grad.shape:
+        raise RuntimeError("expected matching 4D tensors")
+    grad = grad.contiguous()
+    y = y.contiguous()
+    b, np_, sq, sk = grad.shape
+    check(get_lib().mm_softmax_masked_bwd(grad.data_ptr(), y.data_ptr(), float(scale), b, np_, sq, sk,
+                                          dtype_code(grad.dtype), _stream()), "softmax_masked_bwd")
+    return grad
+
+
+def softmax_batch_per_block(sq, sk, b, np_):
+    return get_lib().mm_softmax_batch_per_block(sq, sk, b, np_)
+
+
+# ---------------------------------------------------------------------------- layernorm
+def layernorm_fwd(x, w, b, eps, w2=None, b2=None):
+    """Returns (y, y2|None, mean, rstd).  x: [..., h]."""
+    _need_cuda(x, w, b)
+    h = x.size(-1)
+    x2 = x.contiguous().view(-1, h)
+    rows = x2.size(0)
+    y = torch.empty_like(x2)
+    y2 = torch.empty_like(x2) if w2 is not None else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(get_lib().mm_layernorm_fwd(y.data_ptr(), _ptr(y2), mean.data_ptr(), rstd.data_ptr(), x2.data_ptr(),
+                                     w.data_ptr(), b.data_ptr(), _ptr(w2), _ptr(b2), rows, h, float(eps),
+                                     dtype_code(x.dtype), _stream()), "layernorm_fwd")
+    return y.view(x.shape), (y2.view(x.shape) if y2 is not None else None), mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dy2=None, w2=None, dresidual=None, param_grads=True):
+    """Returns (dx, [dw, db, (dw2, db2)] or None)."""
+    _need_cuda(dy, x, w)
+    h = x.size(-1)
+    x2 = x.contiguous().view(-1, h)
+    rows = x2.size(0)
+    dy = dy.contiguous()
+    dy2 = dy2.contiguous() if dy2 is not None else None
+    dres = dresidual.contiguous() if dresidual is not None else None
+    dx = torch.empty_like(x2)
+    lib = get_lib()
+    nvec = 4 if dy2 is not None else 2
+    partial = None
+    if param_grads:
+        nblk = lib.mm_layernorm_bwd_nblk(rows)
+        partial = torch.empty(nblk * nvec * h, dtype=torch.float32, device=x.device)
+    check(lib.mm_layernorm_bwd(dx.data_ptr(), _ptr(partial), dy.data_ptr(), _ptr(dy2), _ptr(dres), x2.data_ptr(),
+                               w.data_ptr(), _ptr(w2), mean.data_ptr(), rstd.data_ptr(), rows, h, dtype_code(x.dtype),
+                               _stream()), "layernorm_bwd")
+    grads = None
+    if param_grads:
+        import ctypes
+        outs = [torch.empty(h, dtype=x.dtype, device=x.device) for _ in range(nvec)]
+        arr = (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs] + [None] * (4 - nvec))
+        check(lib.mm_layernorm_bwd_finalize(ctypes.cast(arr, ctypes.c_void_p), partial.data_ptr(), nblk, nvec, h,
+                                            dtype_code(x.dtype), _stream()), "layernorm_bwd_finalize")
+        grads = outs
+    return dx.view(x.shape), grads
+
+
+# ---------------------------------------------------------------------------- rotary / gelu / bias-dropout-add
+def rotary_qk_inplace(qkv, cos, sin, s, b, np_, hn, d, offset=0, inverse=False):
+    """qkv: contiguous [s, b, np, 3*hn]; cos/sin: [>=offset+s, d] tables in qkv's dtype."""
+    _need_cuda(qkv, cos, sin)
+    if not qkv.is_contiguous() or qkv.numel() != s * b * np_ * 3 * hn:
+        raise RuntimeError("rotary_qk_inplace: qkv must be contiguous [s, b, np, 3*hn]")
+    if cos.dtype != qkv.dtype or sin.dtype != qkv.dtype or cos.size(-1) != d or cos.numel() < (offset + s) * d:
+        raise RuntimeError("rotary_qk_inplace: cos/sin tables must be [>=offset+s, d] in the activation dtype")
+    check(get_lib().mm_rotary_qk_inplace(qkv.data_ptr(), cos.contiguous().data_ptr(), sin.contiguous().data_ptr(), s, b,
+                                         np_, hn, d, offset, int(bool(inverse)), dtype_code(qkv.dtype), _stream()),
+          "rotary_qk_inplace")
+    return qkv
+
+
+def bias_gelu_fwd(y, bias, mode):
+    _need_cuda(y, bias)
+    y = y.contiguous()
+    cols = y.size(-1)
+    out = torch.empty_like(y)
+    check(get_lib().mm_bias_gelu_fwd(out.data_ptr(), y.data_ptr(), bias.data_ptr(), y.numel() // cols, cols, mode,
+                                     dtype_code(y.dtype), _stream()), "bias_gelu_fwd")
+    return out
+
+
+def bias_gelu_bwd(g, y, bias, mode, out=None):
+    _need_cuda(g, y, bias)
+    g = g.contiguous()
+    y = y.contiguous()
+    cols = y.size(-1)
+    out = torch.empty_like(y) if out is None else out
+    check(get_lib().mm_bias_gelu_bwd(out.data_ptr(), g.data_ptr(), y.data_ptr(), bias.data_ptr(), y.numel() // cols, cols,
+                                     mode, dtype_code(y.dtype), _stream()), "bias_gelu_bwd")
+    return out
+
+
+def bias_dropout_add(x, bias, residual, p, training, seed=0, offset=0, want_mask=False):
+    _need_cuda(x, bias, residual)
+    x = x.contiguous()
+    cols = x.size(-1)
+    if bias is not None:
+        if bias.numel() != cols:
+            raise RuntimeError("bias_dropout_add: bias must be a [cols] vector (an expanded bias is taken by its last dim)")
+        bias = bias.contiguous()
+    residual = residual.contiguous() if residual is not None else None
+    out = torch.empty_like(x)
+    keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if (want_mask and training and p > 0) else None
+    check(get_lib().mm_bias_dropout_add(out.data_ptr(), x.data_ptr(), _ptr(bias), _ptr(residual), _ptr(keep),
+                                        x.numel() // cols, cols, float(p), int(bool(training)), int(seed), int(offset),
+                                        dtype_code(x.dtype), _stream()), "bias_dropout_add")
+    return (out, keep) if want_mask else out
+
+
+def colsum(x):
+    """[rows, cols] -> [cols] (bias gradient)."""
+    _need_cuda(x)
+    cols = x.size(-1)
+    x2 = x.contiguous().view(-1, cols)
+    lib = get_lib()
+    partial = torch.empty(lib.mm_colsum_nblk(x2.size(0)) * cols, dtype=torch.float32, device=x.device)
+    out = torch.empty(cols, dtype=x.dtype, device=x.device)
+    check(lib.mm_colsum(out.data_ptr(), partial.data_ptr(), x2.data_ptr(), x2.size(0), cols, dtype_code(x.dtype), _stream()),
+          "colsum")
+    return out
+
+
+def transpose2d(x):
+    _need_cuda(x)
+    if x.dim() != 2 or x.element_size() != 2:
+        raise RuntimeError("transpose2d: expected a 2D tensor of 2-byte elements")
+    x = x.contiguous()
+    out = torch.empty(x.size(1), x.size(0), dtype=x.dtype, device=x.device)
+    check(get_lib().mm_transpose2d(out.data_ptr(), x.data_ptr(), x.size(0), x.size(1), _stream()), "transpose2d")
+    return out
+
+
+def add(a, b, c=None, out=None):
+    _need_cuda(a, b, c)
+    a, b = a.contiguous(), b.contiguous()
+    c = c.contiguous() if c is not None else None
+    out = torch.empty_like(a) if out is None else out
+    check(get_lib().mm_add(out.data_ptr(), a.data_ptr(), b.data_ptr(), _ptr(c), a.numel(), dtype_code(a.dtype), _stream()),
+          "add")
+    return out
+
+
+# ---------------------------------------------------------------------------- GEMM
+def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, want_aux=False):
+    """C[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue.  a: [..., K] (flattened to 2D), b: [N, K].
+    Returns C (and the pre-bias product ``aux`` for the GeLU epilogues)."""
+    _need_cuda(a, b, bias, residual)
+    K = a.size(-1)
+    a2 = a.contiguous().view(-1, K)
+    b = b.contiguous()
+    M, N = a2.size(0), b.size(0)
+    if b.size(1) != K:
+        raise RuntimeError(f"gemm_nt: inner dimensions differ ({K} vs {b.size(1)})")
+    if bias is None and epilogue != _lib.EPI_NONE:
+        raise RuntimeError("gemm_nt: this epilogue needs a bias")
+    if bias is not None and epilogue == _lib.EPI_NONE:
+        epilogue = _lib.EPI_BIAS
+    c = torch.empty(M, N, dtype=a.dtype, device=a.device) if out is None else out
+    aux = None
+    if epilogue in (_lib.EPI_BIAS_GELU_TANH, _lib.EPI_BIAS_GELU_ERF):
+        aux = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    if residual is not None:
+        residual = residual.contiguous()
+    check(get_lib().mm_gemm_nt(c.data_ptr(), _ptr(aux), a2.data_ptr(), b.data_ptr(), _ptr(bias), _ptr(residual), M, N, K,
+                               K, K, N, epilogue, dtype_code(a.dtype), _stream()), "gemm_nt")
+    c = c.view(*a.shape[:-1], N)
+    if aux is not None:
+        return c, aux.view(*a.shape[:-1], N)
+    return (c, None) if want_aux else c
+
+
+# ---------------------------------------------------------------------------- attention
+def attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask=None):
+    """qkv: contiguous [s, b, np, 3*hn] (post-rotary).  mask None => implicit causal; otherwise a
+    uint8/bool [1|b, 1, s, s] tensor (1 = masked, filled with -10000).  Returns (ctx [s, b, np*hn], lse [b, np, s])."""
+    _need_cuda(qkv, mask)
+    if not qkv.is_contiguous() or qkv.numel() != s * b * np_ * 3 * hn:
+        raise RuntimeError("attn_fwd: qkv must be contiguous [s, b, np, 3*hn]")
+    ctx = torch.empty(s, b, np_ * hn, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(b, np_, s, dtype=torch.float32, device=qkv.device)
+    m, mode, mb = _mask_args(mask, s, b)
+    check(get_lib().mm_attn_fwd(ctx.data_ptr(), lse.data_ptr(), qkv.data_ptr(), _ptr(m), mode, mb, s, b, np_, hn,
+                                float(softmax_scale), dtype_code(qkv.dtype), _stream()), "attn_fwd")
+    return ctx, lse
+
+
+def attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, softmax_scale, mask=None):
+    _need_cuda(dctx, ctx, lse, qkv, mask)
+    dctx = dctx.contiguous()
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(b, np_, s, dtype=torch.float32, device=qkv.device)
+    m, mode, mb = _mask_args(mask, s, b)
+    check(get_lib().mm_attn_bwd(dqkv.data_ptr(), delta.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                qkv.data_ptr(), _ptr(m), mode, mb, s, b, np_, hn, float(softmax_scale),
+                                dtype_code(qkv.dtype), _stream()), "attn_bwd")
+    return dqkv
+
+
+def _mask_args(mask, s, b):
+    if mask is None:
+        return None, 0, 1
+    if mask.dim() != 4 or mask.size(1) != 1 or mask.size(2) != s or mask.size(3) != s or mask.size(0) not in (1, b):
+        raise RuntimeError(f"attention mask must be [1|b, 1, s, s], got {tuple(mask.shape)}")
+    m = mask.contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+    return m, 1, m.size(0)

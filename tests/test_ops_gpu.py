@@ -1,0 +1,300 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (multimodal_amd.ops -> libmm_hip.so),
+against the CPU oracle (oracle/neox_layer_oracle.py) and the golden fixtures produced by the reference."""
+import glob
+import os
+
+import pytest
+import torch
+
+import golden_io
+from oracle import neox_layer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+@pytest.fixture(scope="module")
+def ops(cuda_device):
+    from multimodal_amd import ops as _ops
+    return _ops
+
+
+def ulp_close(a, b, dtype, ulps=1, atol=1e-6):
+    """|a-b| <= ulps * 2^-(mantissa) * |b| + atol."""
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    a, b = a.float().cpu(), b.float().cpu()
+    bad = (a - b).abs() > ulps * eps * b.abs() + atol
+    assert not bad.any(), f"{int(bad.sum())} / {bad.numel()} elements differ; max abs diff {(a - b).abs().max()}"
+
+
+# ------------------------------------------------------------------ hardware probe
+def test_tr_read_semantics(ops, cuda_device):
+    """ds_read_b64_tr_b16: lane i of a 16-lane group receives column i of a 4-row x 16-col block, row q in element q."""
+    import ctypes
+    from multimodal_amd._lib import get_lib, check
+    tile = torch.arange(16 * 64, dtype=torch.int16).view(16, 64)
+    row0 = torch.tensor([0, 4, 8, 12], dtype=torch.int32)
+    col0 = torch.tensor([0, 16, 32, 48], dtype=torch.int32)
+    out = torch.zeros(64, 4, dtype=torch.int16, device=cuda_device)
+    check(get_lib().mm_debug_probe_tr_read(out.data_ptr(), tile.to(cuda_device).data_ptr(), row0.to(cuda_device).data_ptr(),
+                                           col0.to(cuda_device).data_ptr(), torch.cuda.current_stream().cuda_stream))
+    out = out.cpu()
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        want = [int(tile[row0[g] + q, col0[g] + i]) for q in range(4)]
+        assert out[lane].tolist() == want, (lane, out[lane].tolist(), want)
+
+
+# ------------------------------------------------------------------ softmax
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("s", [24, 64, 128, 520, 1024, 2048])
+@pytest.mark.parametrize("scale", [1.0, 0.5])
+def test_softmax_causal_fwd_bwd(ops, cuda_device, dt, s, scale):
+    torch.manual_seed(s)
+    nb = 4 if s <= 1024 else 2
+    x = (torch.randn(nb, s, s) * 3).to(DT[dt])
+    g = torch.randn(nb, s, s).to(DT[dt])
+    y_ref = O.softmax_causal_fused_fwd(x, scale)
+    y = ops.softmax_causal_fwd(x.to(cuda_device), scale)
+    ulp_close(y, y_ref, DT[dt], ulps=1, atol=1e-7)
+    upper = torch.triu(torch.ones(s, s, dtype=torch.bool), 1)
+    assert torch.all(y.cpu()[:, upper] == 0)
+    gin = g.to(cuda_device).clone()
+    dx = ops.softmax_causal_bwd(gin, y_ref.to(cuda_device), scale)
+    assert dx.data_ptr() == gin.data_ptr(), "backward must write in place into output_grads"
+    dx_ref = O.softmax_fused_bwd(g, y_ref, scale, causal=True)
+    ulp_close(dx, dx_ref, DT[dt], ulps=1, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("sq,sk", [(8, 24), (64, 64), (128, 512), (32, 1000), (16, 2048)])
+@pytest.mark.parametrize("mask_b", [1, 2])
+def test_softmax_masked_fwd_bwd(ops, cuda_device, dt, sq, sk, mask_b):
+    torch.manual_seed(sq * sk)
+    b, np_ = 2, 3
+    x = (torch.randn(b, np_, sq, sk) * 3).to(DT[dt])
+    mask = torch.rand(mask_b, 1, sq, sk) < 0.3
+    mask[..., 0, :] = True  # one fully masked row: -10000 fill must give the uniform distribution, not NaN
+    y_ref = O.softmax_masked_fused_fwd(x, mask, 0.5)
+    y = ops.softmax_masked_fwd(x.to(cuda_device), mask.to(cuda_device), 0.5)
+    ulp_close(y, y_ref, DT[dt], ulps=1, atol=1e-7)
+    g = torch.randn(b, np_, sq, sk).to(DT[dt])
+    dx = ops.softmax_masked_bwd(g.to(cuda_device).clone(), y_ref.to(cuda_device), 0.5)
+    ulp_close(dx, O.softmax_fused_bwd(g, y_ref, 0.5, causal=False), DT[dt], ulps=1, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(golden_io.HERE, "op_softmax_eager_*.npz"))))
+def test_softmax_vs_reference_eager_fixture(ops, cuda_device, name):
+    """The reference's own fused-vs-eager bar: mean |diff| <= 1e-3 (tests/model/test_fused_kernels.py:122-142)."""
+    t, meta = golden_io.load(name)
+    x = t["x"]
+    if x.dtype == torch.float32:
+        pytest.skip("fused kernels take fp16/bf16 only")
+    scale = meta["scale"] if meta["scale"] is not None else 1.0
+    b, np_, sk, _ = x.shape
+    y = ops.softmax_causal_fwd(x.view(-1, sk, sk).to(cuda_device), scale).view(b, np_, sk, sk).cpu()
+    assert (y.float() - t["probs_causal"].float()).abs().mean() <= 1e-3
+    ym = ops.softmax_masked_fwd(x.to(cuda_device), t["mask_general"].to(cuda_device), scale).cpu()
+    assert (ym.float() - t["probs_general"].float()).abs().mean() <= 1e-3
+
+
+def test_softmax_batch_per_block_and_errors(ops, cuda_device):
+    for sk in (17, 64, 128, 129, 512, 2048):
+        assert ops.softmax_batch_per_block(64, sk, 4, 16) == O.softmax_batch_per_block(64, sk, 4, 16)
+    with pytest.raises(RuntimeError):
+        ops.softmax_causal_fwd(torch.zeros(2, 8, 8, dtype=torch.float32, device=cuda_device), 1.0)  # dtype must be 16-bit
+    with pytest.raises(RuntimeError):
+        ops.softmax_causal_fwd(torch.zeros(1, 2056, 2056, dtype=torch.bfloat16, device=cuda_device), 1.0)  # s > 2048
+    with pytest.raises(RuntimeError):
+        ops.softmax_causal_fwd(torch.zeros(2, 8, 8, dtype=torch.bfloat16), 1.0)  # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------ layernorm
+@pytest.mark.parametrize("h", [512, 1024])
+def test_layernorm_fixture(ops, cuda_device, h):
+    t, meta = golden_io.load(f"op_layernorm_h{h}_bf16")
+    d = {k: v.to(cuda_device) for k, v in t.items()}
+    y, _, mean, rstd = ops.layernorm_fwd(d["x"], d["w"], d["b"], meta["eps"])
+    ulp_close(y, t["y"], torch.bfloat16, ulps=1, atol=1e-6)
+    dx, grads = ops.layernorm_bwd(d["dy"], d["x"], d["w"], mean, rstd)
+    ulp_close(dx, t["dx"], torch.bfloat16, ulps=2, atol=2e-3)
+    ulp_close(grads[0], t["dw"], torch.bfloat16, ulps=2, atol=2e-2)
+    ulp_close(grads[1], t["db"], torch.bfloat16, ulps=2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("rows,h", [(7, 128), (1024, 1024), (300, 2304), (130, 4096), (64, 8192)])
+def test_layernorm_dual_and_residual(ops, cuda_device, dt, rows, h):
+    torch.manual_seed(h + rows)
+    dtype = DT[dt]
+    x = (torch.randn(rows, h) * 2 + 0.3).to(dtype)
+    w1, b1, w2, b2 = [(torch.randn(h) * 0.2 + (1 if i % 2 == 0 else 0)).to(dtype) for i in range(4)]
+    dy1, dy2, dres = [torch.randn(rows, h).to(dtype) for _ in range(3)]
+    xr = x.clone().requires_grad_(True)
+    ps = [p.clone().requires_grad_(True) for p in (w1, b1, w2, b2)]
+    y1_ref = O.layer_norm(xr.float(), ps[0].float(), ps[1].float())
+    y2_ref = O.layer_norm(xr.float(), ps[2].float(), ps[3].float())
+    torch.autograd.backward([y1_ref, y2_ref, xr.float()], [dy1.float(), dy2.float(), dres.float()])
+    g = lambda t_: t_.to(cuda_device)
+    y1, y2, mean, rstd = ops.layernorm_fwd(g(x), g(w1), g(b1), 1e-5, g(w2), g(b2))
+    ulp_close(y1, y1_ref.detach().to(dtype), dtype, ulps=1, atol=1e-6)
+    ulp_close(y2, y2_ref.detach().to(dtype), dtype, ulps=1, atol=1e-6)
+    dx, grads = ops.layernorm_bwd(g(dy1), g(x), g(w1), mean, rstd, dy2=g(dy2), w2=g(w2), dresidual=g(dres))
+    scale = xr.grad.abs().max()
+    assert (dx.float().cpu() - xr.grad.float()).abs().max() <= 2 ** -7 * scale
+    for got, ref in zip(grads, ps):
+        assert (got.float().cpu() - ref.grad.float()).abs().max() <= 2 ** -6 * ref.grad.abs().max() + 1e-3
+    dx_only, none = ops.layernorm_bwd(g(dy1), g(x), g(w1), mean, rstd, param_grads=False)
+    assert none is None and dx_only.shape == x.shape
+
+
+# ------------------------------------------------------------------ rotary / gelu / bias-dropout-add
+@pytest.mark.parametrize("d", [16, 64])
+@pytest.mark.parametrize("dt", ["bf16"])
+def test_rotary_fixture_bit_exact(ops, cuda_device, d, dt):
+    t, _ = golden_io.load(f"op_rotary_apply_d{d}_{dt}")
+    s, b, np_, hn = t["q"].shape
+    v = torch.randn(s, b, np_, hn).to(DT[dt])
+    qkv = torch.cat([t["q"], t["k"], v], dim=-1).contiguous().to(cuda_device)
+    ops.rotary_qk_inplace(qkv, t["cos"].to(cuda_device), t["sin"].to(cuda_device), s, b, np_, hn, d)
+    q2, k2, v2 = qkv.cpu().split(hn, dim=-1)
+    assert torch.equal(q2, t["q_out"]) and torch.equal(k2, t["k_out"]) and torch.equal(v2, v)
+    dqkv = torch.cat([t["dq_out"], t["dk_out"], v], dim=-1).contiguous().to(cuda_device)
+    ops.rotary_qk_inplace(dqkv, t["cos"].to(cuda_device), t["sin"].to(cuda_device), s, b, np_, hn, d, inverse=True)
+    dq, dk, _ = dqkv.cpu().split(hn, dim=-1)
+    assert torch.equal(dq, t["dq"]) and torch.equal(dk, t["dk"])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("d,hn,offset", [(16, 64, 0), (64, 64, 3), (128, 128, 0), (32, 128, 5)])
+def test_rotary_vs_oracle(ops, cuda_device, dt, d, hn, offset):
+    torch.manual_seed(d)
+    dtype = DT[dt]
+    s, b, np_ = 33, 2, 3
+    qkv = torch.randn(s, b, np_, 3 * hn).to(dtype)
+    cos, sin = O.rotary_tables(offset + s, d, 10000, dtype)
+    q, k, v = qkv.split(hn, dim=-1)
+    qr, kr = O.apply_rotary(q[..., :d], k[..., :d], cos, sin, offset=offset)
+    ref = torch.cat([qr, q[..., d:], kr, k[..., d:], v], dim=-1)
+    got = ops.rotary_qk_inplace(qkv.to(cuda_device).contiguous(), cos.to(cuda_device), sin.to(cuda_device), s, b, np_, hn, d, offset)
+    assert torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_bias_gelu(ops, cuda_device, dt):
+    dtype = DT[dt]
+    t, _ = golden_io.load("op_bias_gelu_bf16")
+    y, bias, g = [t[k].to(dtype) for k in ("y", "bias", "g")]
+    dev = lambda a: a.to(cuda_device)
+    yf, bf, gf = y.float(), bias.float(), g.float()
+    out = ops.bias_gelu_fwd(dev(y), dev(bias), 0)
+    ulp_close(out, O.bias_gelu_tanh(bf, yf).to(dtype), dtype, ulps=1, atol=1e-6)
+    dy = ops.bias_gelu_bwd(dev(g), dev(y), dev(bias), 0)
+    ulp_close(dy, O.bias_gelu_tanh_back(gf, bf, yf).to(dtype), dtype, ulps=1, atol=1e-5)
+    out_e = ops.bias_gelu_fwd(dev(y), dev(bias), 1)
+    ulp_close(out_e, O.gelu_erf_bias(y, bias), dtype, ulps=1, atol=1e-6)
+    y2 = y.clone().requires_grad_(True)
+    O.gelu_erf_bias(y2.float(), bf).backward(gf)
+    dye = ops.bias_gelu_bwd(dev(g), dev(y), dev(bias), 1)
+    ulp_close(dye, y2.grad.to(dtype), dtype, ulps=2, atol=1e-4)
+    if dt == "bf16":  # and against what the reference itself produced
+        ulp_close(out, t["out_tanh"], dtype, ulps=2, atol=1e-5)
+        ulp_close(out_e, t["out_erf"], dtype, ulps=1, atol=1e-6)
+
+
+def test_bias_dropout_add(ops, cuda_device):
+    t, _ = golden_io.load("op_bias_dropout_add_bf16")
+    dev = lambda a: a.to(cuda_device)
+    o1 = ops.bias_dropout_add(dev(t["x"]), dev(t["bias"]), dev(t["residual"]), 0.0, True)
+    o2 = ops.bias_dropout_add(dev(t["x"]), dev(t["bias"]), None, 0.0, True)
+    o3 = ops.bias_dropout_add(dev(t["x"]), dev(t["bias"]), dev(t["residual"]), 0.1, False)
+    assert torch.equal(o1.cpu(), t["out_res"]) and torch.equal(o2.cpu(), t["out_nores"]) and torch.equal(o3.cpu(), t["out_eval"])
+    # p > 0: keep-rate, scaling, determinism in (seed, offset)
+    x = torch.ones(512, 1024, dtype=torch.bfloat16, device=cuda_device)
+    a, keep = ops.bias_dropout_add(x, None, None, 0.25, True, seed=7, offset=1, want_mask=True)
+    b_, _ = ops.bias_dropout_add(x, None, None, 0.25, True, seed=7, offset=1, want_mask=True)
+    c_, _ = ops.bias_dropout_add(x, None, None, 0.25, True, seed=8, offset=1, want_mask=True)
+    assert torch.equal(a, b_) and not torch.equal(a, c_)
+    rate = keep.float().mean().item()
+    assert abs(rate - 0.75) < 0.01
+    assert torch.equal(a.float(), keep.float() * torch.tensor(1 / 0.75).bfloat16().float())
+
+
+def test_colsum_transpose_add(ops, cuda_device):
+    torch.manual_seed(0)
+    x = torch.randn(1000, 384).bfloat16()
+    got = ops.colsum(x.to(cuda_device)).float().cpu()
+    ref = x.float().sum(0)
+    assert (got - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+    xt = ops.transpose2d(x.to(cuda_device))
+    assert torch.equal(xt.cpu(), x.t().contiguous())
+    y = torch.randn(1000, 384).bfloat16()
+    z = torch.randn(1000, 384).bfloat16()
+    assert torch.equal(ops.add(x.to(cuda_device), y.to(cuda_device)).cpu(), x + y)
+    ulp_close(ops.add(x.to(cuda_device), y.to(cuda_device), z.to(cuda_device)), (x.float() + y.float() + z.float()), torch.bfloat16)
+
+
+# ------------------------------------------------------------------ GEMM
+def _gemm_ref(a, b, bias, epi, residual):
+    acc = a.double() @ b.double().t()
+    dt = a.dtype
+    if epi == "none":
+        out = acc
+    elif epi == "bias":
+        out = acc + bias.double()
+    elif epi == "relu":
+        out = torch.relu((acc + bias.double()).to(dt).double())
+    else:
+        u = acc.to(dt)
+        xx = u.double() + bias.double()
+        out = O.bias_gelu_tanh(torch.zeros_like(xx), xx) if epi == "gelu_tanh" else torch.nn.functional.gelu(xx.to(dt).double())
+    if residual is not None:
+        out = out.to(dt).double() + residual.double()
+    return out
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 132, 192), (8, 4, 64), (1024, 3072, 1024), (300, 50304 // 16, 256)])
+@pytest.mark.parametrize("epi", ["none", "bias", "gelu_tanh", "gelu_erf", "relu"])
+def test_gemm_nt(ops, cuda_device, dt, M, N, K, epi):
+    from multimodal_amd import _lib
+    torch.manual_seed(M + N + K)
+    dtype = DT[dt]
+    a = torch.randn(M, K).to(dtype)
+    b = (torch.randn(N, K) / K ** 0.5).to(dtype)
+    bias = torch.randn(N).to(dtype)
+    res = torch.randn(M, N).to(dtype) if epi in ("bias", "relu") else None
+    code = {"none": _lib.EPI_NONE, "bias": _lib.EPI_BIAS, "gelu_tanh": _lib.EPI_BIAS_GELU_TANH,
+            "gelu_erf": _lib.EPI_BIAS_GELU_ERF, "relu": _lib.EPI_BIAS_RELU}[epi]
+    dev = lambda t_: None if t_ is None else t_.to(cuda_device)
+    out = ops.gemm_nt(dev(a), dev(b), None if epi == "none" else dev(bias), code, residual=dev(res))
+    aux = None
+    if isinstance(out, tuple):
+        out, aux = out
+    ref = _gemm_ref(a, b, bias, epi, res)
+    err = (out.double().cpu() - ref).abs()
+    tol = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * ref.abs() + 2e-2
+    assert (err <= tol).all(), f"max err {err.max()} at {epi}"
+    if aux is not None:
+        uref = (a.double() @ b.double().t())
+        assert ((aux.double().cpu() - uref).abs() <= 2.0 ** -7 * uref.abs() + 1e-2).all()
+
+
+def test_gemm_exact_small_integers(ops, cuda_device):
+    """Asymmetric integer operands (exact in bf16 and in the fp32 accumulator): catches any transposed/permuted fragment."""
+    M, N, K = 256, 128, 128
+    a = (torch.arange(M * K).view(M, K) % 7 - 3).float()
+    b = ((torch.arange(N * K).view(N, K) * 5) % 11 - 5).float()
+    out = ops.gemm_nt(a.bfloat16().to(cuda_device), b.bfloat16().to(cuda_device))
+    ref = a @ b.t()
+    assert torch.equal(out.float().cpu(), ref.bfloat16().float())
+
+
+def test_gemm_rejects_bad_shapes(ops, cuda_device):
+    a = torch.zeros(16, 48, dtype=torch.bfloat16, device=cuda_device)
+    b = torch.zeros(8, 48, dtype=torch.bfloat16, device=cuda_device)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm_nt(a, b)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(torch.zeros(16, 64, device=cuda_device), torch.zeros(8, 64, device=cuda_device))  # fp32

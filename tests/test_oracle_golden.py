@@ -1,0 +1,216 @@
+"""Pins the CPU oracle (oracle/neox_layer_oracle.py) against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  Runs on CPU (-m "not gpu")."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io
+import golden_params
+from oracle import neox_layer_oracle as O
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def eq(a, b):
+    return torch.equal(a, b)
+
+
+@pytest.mark.parametrize("h", [512, 1024])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_layernorm_matches_reference(h, dt):
+    t, meta = golden_io.load(f"op_layernorm_h{h}_{dt}")
+    x = t["x"].clone().requires_grad_(True)
+    w = t["w"].clone().requires_grad_(True)
+    b = t["b"].clone().requires_grad_(True)
+    y = O.layer_norm(x, w, b, meta["eps"])
+    y.backward(t["dy"])
+    assert eq(y.detach(), t["y"]) and eq(x.grad, t["dx"]) and eq(w.grad, t["dw"]) and eq(b.grad, t["db"])
+
+
+@pytest.mark.parametrize("d", [16, 64, 128])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+def test_rotary_tables_bit_exact(d, dt):
+    t, meta = golden_io.load(f"op_rotary_table_d{d}_{dt}")
+    cos, sin = O.rotary_tables(meta["seq_len"], d, meta["base"], DT[dt])
+    assert eq(cos, t["cos"]) and eq(sin, t["sin"])
+    if dt == "bf16":  # the reference's quirk: bf16 positions above 256 are rounded
+        cos32, _ = O.rotary_tables(meta["seq_len"], d, meta["base"], torch.float32)
+        assert not torch.allclose(cos.float(), cos32, atol=1e-2)
+
+
+@pytest.mark.parametrize("d", [16, 64])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_rotary_apply_bit_exact(d, dt):
+    t, _ = golden_io.load(f"op_rotary_apply_d{d}_{dt}")
+    q = t["q"].clone().requires_grad_(True)
+    k = t["k"].clone().requires_grad_(True)
+    hn = q.size(-1)
+    qr, kr = O.apply_rotary(q[..., :d], k[..., :d], t["cos"], t["sin"])
+    if d < hn:
+        qr = torch.cat((qr, q[..., d:]), -1)
+        kr = torch.cat((kr, k[..., d:]), -1)
+    torch.autograd.backward([qr, kr], [t["dq_out"], t["dk_out"]])
+    assert eq(qr.detach(), t["q_out"]) and eq(kr.detach(), t["k_out"])
+    assert eq(q.grad, t["dq"]) and eq(k.grad, t["dk"])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_bias_gelu_matches_reference(dt):
+    t, _ = golden_io.load(f"op_bias_gelu_{dt}")
+    y = t["y"].clone().requires_grad_(True)
+    bias = t["bias"].clone().requires_grad_(True)
+    out = O.bias_gelu_impl(y, bias)
+    out.backward(t["g"])
+    # the reference op is TorchScript: allow 1 ulp of the storage dtype for fusion-order differences
+    tol = dict(rtol=0, atol=0) if dt == "f32" else dict(rtol=2 ** -7, atol=1e-6)
+    if dt == "f32":
+        torch.testing.assert_close(out.detach(), t["out_tanh"], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(y.grad, t["dy_tanh"], rtol=1e-5, atol=1e-6)
+    else:
+        torch.testing.assert_close(out.detach().float(), t["out_tanh"].float(), **tol)
+        torch.testing.assert_close(y.grad.float(), t["dy_tanh"].float(), rtol=2 ** -6, atol=1e-5)
+    y2 = t["y"].clone().requires_grad_(True)
+    o2 = O.gelu_erf_bias(y2, t["bias"])
+    o2.backward(t["g"])
+    assert eq(o2.detach(), t["out_erf"]) and eq(y2.grad, t["dy_erf"])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_bias_dropout_add_bit_exact(dt):
+    t, _ = golden_io.load(f"op_bias_dropout_add_{dt}")
+    x, bias, res = t["x"], t["bias"], t["residual"]
+    assert eq(O.bias_dropout_add(x, bias.expand_as(x), res, 0.0, True), t["out_res"])
+    assert eq(O.bias_dropout_add(x, bias.expand_as(x), None, 0.0, True), t["out_nores"])
+    assert eq(O.bias_dropout_add(x, bias.expand_as(x), res, 0.1, False), t["out_eval"])
+
+
+SOFTMAX_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(golden_io.HERE, "op_softmax_eager_*.npz")))
+
+
+@pytest.mark.parametrize("name", SOFTMAX_FILES)
+def test_softmax_eager_bit_exact_and_fused_restatement_close(name):
+    t, meta = golden_io.load(name)
+    x = t["x"]
+    sk = x.size(-1)
+    xin = x.clone().requires_grad_(True)
+    p = O.softmax_eager(xin * 1.0, O.causal_mask(sk), meta["scale"], meta["softmax_in_fp32"])
+    p.backward(t["dy"])
+    assert eq(p.detach(), t["probs_causal"]) and eq(xin.grad, t["dx_causal"])
+    p2 = O.softmax_eager(x.clone(), t["mask_general"], meta["scale"], meta["softmax_in_fp32"])
+    assert eq(p2, t["probs_general"])
+    if x.dtype != torch.float32:
+        # fused-kernel restatements vs the reference's eager path: the reference's own bar is mean|diff| <= 1e-3
+        scale = meta["scale"] if meta["scale"] is not None else 1.0
+        b, np_ = x.shape[:2]
+        pf = O.softmax_causal_fused_fwd(x.view(-1, sk, sk), scale).view(b, np_, sk, sk)
+        assert (pf.float() - t["probs_causal"].float()).abs().mean() <= 1e-3
+        assert torch.all(pf[..., torch.triu(torch.ones(sk, sk, dtype=torch.bool), 1)] == 0)
+        pm = O.softmax_masked_fused_fwd(x, t["mask_general"], scale)
+        assert (pm.float() - t["probs_general"].float()).abs().mean() <= 1e-3
+        gb = O.softmax_fused_bwd(t["dy"].view(-1, sk, sk), pf.view(-1, sk, sk), scale, causal=True).view_as(x)
+        assert (gb.float() - t["dx_causal"].float()).abs().mean() <= 2e-3
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_linears_tp1_bit_exact(dt):
+    t, meta = golden_io.load(f"op_linear_tp1_{dt}")
+    x = t["x"].clone().requires_grad_(True)
+    cw = t["col_w"].clone().requires_grad_(True)
+    cb = t["col_b"].clone().requires_grad_(True)
+    rw = t["row_w"].clone().requires_grad_(True)
+    yc, bc = O.column_parallel_linear(x, cw, cb, skip_bias_add=False)
+    (yr,), br = O.row_parallel_linear([yc], [rw], t["row_b"], skip_bias_add=True)
+    yr.backward(t["dy"])
+    assert bc is None and eq(br, t["row_b"])
+    assert eq(yc.detach(), t["y_col"]) and eq(yr.detach(), t["y_row"])
+    assert eq(x.grad, t["dx"]) and eq(cw.grad, t["d_col_w"]) and eq(cb.grad, t["d_col_b"]) and eq(rw.grad, t["d_row_w"])
+
+
+def _layer_files(tp):
+    pat = os.path.join(golden_io.HERE, f"layer_*_tp{tp}{'_r0' if tp > 1 else ''}.npz")
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(pat))
+
+
+def _run_oracle_layer(meta, x, dy, tp):
+    dt = DT[meta["dtype"]]
+    master = golden_params.master_params(np.random.default_rng(meta["seed"]), meta["h"])
+    # replicated parameters (LayerNorm, Row-linear biases) are ONE tensor shared by every simulated rank: their
+    # gradient is then the all-reduced one each reference rank sees (mpu/mappings.py:121-123)
+    shared = {k: master[k].to(dt).requires_grad_(True) for k in golden_params.PARAM_ORDER
+              if golden_params.shard(k, master[k], 0, 2) is master[k]}
+    shards = []
+    for r in range(tp):
+        shards.append({k: shared[k] if k in shared else golden_params.shard(k, master[k], r, tp).to(dt).requires_grad_(True)
+                       for k in golden_params.PARAM_ORDER})
+    cfg = O.LayerConfig(meta["h"], meta["n"], rotary_pct=meta["rotary_pct"], gpt_j_residual=meta["gpt_j_residual"],
+                        bias_gelu_fusion=meta["bias_gelu_fusion"], tp=tp)
+    xin = x.clone().requires_grad_(True)
+    y = O.layer_forward(cfg, shards, xin, O.causal_mask(meta["s"]))
+    y.backward(dy)
+    return y.detach(), xin.grad, shards
+
+
+@pytest.mark.parametrize("name", _layer_files(1))
+def test_layer_tp1_matches_reference(name):
+    t, meta = golden_io.load(name)
+    y, dx, shards = _run_oracle_layer(meta, t["x"], t["dy"], 1)
+    psum = float(sum(p.detach().double().abs().sum() for p in shards[0].values()))
+    assert abs(psum - meta["param_abs_sum"]) <= 1e-9 * meta["param_abs_sum"], "seeded parameters do not regenerate"
+    if meta["dtype"] == "f32":
+        tol = dict(rtol=1e-5, atol=1e-5)
+    else:  # bf16 eager: identical op sequence -> identical roundings, except the TorchScript gelu
+        tol = dict(rtol=2 ** -6, atol=2e-2) if meta["bias_gelu_fusion"] else dict(rtol=0, atol=0)
+    torch.testing.assert_close(y.float(), t["y"].float(), **tol)
+    torch.testing.assert_close(dx.float(), t["dx"].float(), **(tol if tol["atol"] else dict(rtol=2 ** -6, atol=2e-2)))
+    for k in golden_params.PARAM_ORDER:
+        if "g." + k in t:
+            g = shards[0][k].grad.float()
+            ref = t["g." + k].float()
+            scale = ref.abs().max().clamp_min(1e-6)
+            assert (g - ref).abs().max() / scale <= (1e-4 if meta["dtype"] == "f32" else 3e-2), k
+
+
+@pytest.mark.parametrize("name", _layer_files(2))
+def test_layer_tp2_matches_reference(name):
+    t0, meta = golden_io.load(name)
+    t1, _ = golden_io.load(name[:-1] + "1")
+    y, dx, shards = _run_oracle_layer(meta, t0["x"], t0["dy"], 2)
+    tol = dict(rtol=1e-5, atol=1e-5) if meta["dtype"] == "f32" else dict(rtol=2 ** -6, atol=3e-2)
+    for t in (t0, t1):  # both ranks hold the same y / dx
+        torch.testing.assert_close(y.float(), t["y"].float(), **tol)
+        torch.testing.assert_close(dx.float(), t["dx"].float(), **tol)
+    for r, t in enumerate((t0, t1)):
+        for k in ("attention.query_key_value.bias", "mlp.dense_h_to_4h.bias", "attention.dense.bias", "input_layernorm.weight"):
+            g = shards[r][k].grad.float()
+            if k == "attention.dense.bias" and meta["gpt_j_residual"]:
+                g = g / 2  # gpt-j: every rank adds its own copy of the bias, so a rank's grad is 1/tp of the shared tensor's
+            ref = t["g." + k].float()
+            assert (g - ref).abs().max() / ref.abs().max().clamp_min(1e-6) <= (1e-4 if meta["dtype"] == "f32" else 3e-2), (r, k)
+
+
+def test_gptj_tp2_counts_row_biases_twice():
+    """with gpt_j_residual the Row-linear biases are added on every rank before the single reduce."""
+    h, n, s, b = 128, 2, 16, 1
+    master = golden_params.master_params(np.random.default_rng(5), h)
+    x = golden_params.rng_t(np.random.default_rng(6), (s, b, h))
+    outs = {}
+    for tp in (1, 2):
+        cfg = O.LayerConfig(h, n, rotary_pct=0.25, gpt_j_residual=True, bias_gelu_fusion=True, tp=tp)
+        shards = [{k: golden_params.shard(k, master[k], r, tp) for k in golden_params.PARAM_ORDER} for r in range(tp)]
+        outs[tp] = O.layer_forward(cfg, shards, x, O.causal_mask(s))
+    extra = master["attention.dense.bias"] + master["mlp.dense_4h_to_h.bias"]
+    torch.testing.assert_close(outs[2] - outs[1], extra.expand_as(x), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_stack_loss_curve_matches_reference(dt):
+    from tests.stack_harness import run_oracle_stack
+    t, meta = golden_io.load(f"stack_L2_{dt}")
+    losses = run_oracle_stack(meta, t["tokens"], t["loss_mask"], DT[dt])
+    ref = t["losses"].tolist()
+    tol = 2e-4 if dt == "f32" else 3e-2
+    assert max(abs(a - b) for a, b in zip(losses, ref)) <= tol, (losses, ref)
+    assert losses[-1] < losses[0] * 0.2  # and it trains (the reference's own bar: loss goes down)
