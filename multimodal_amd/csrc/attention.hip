@@ -1,11 +1,617 @@
-// attention.hip - placeholder until the fused attention kernels land (next commit).
+// attention.hip - fused (flash-style) self-attention forward and backward for gfx950.
+//
+// Replaces ParallelSelfAttention.attention + the permute behind it (reference
+// megatron/model/transformer.py:315-416, 623-630): scores = q.k^T / sqrt(hn), mask, softmax, P.V -
+// without ever materialising the [b*np, s, s] score tensor (512 MiB per layer at the 410M shape).
+// Reads q/k/v straight out of the fused QKV activation [s, b, np, 3*hn] and writes the context in
+// the layer's [s, b, np*hn] layout, so the split / transpose / permute copies disappear as well.
+//
+// MI355X structure (all three kernels share it):
+//   * workgroup = 4 waves; a wave owns 32 rows of the "resident" operand (32 queries in fwd / dQ,
+//     32 keys in dK/dV) whose fragments live in registers for the whole kernel;
+//   * the streamed operand arrives in 64-row tiles, global -> registers -> LDS (issue early, write late,
+//     double-buffered LDS, one barrier per tile);
+//   * MFMA 32x32x16 with the resident rows on the LANE index of every score tile ("swapped QK^T"):
+//     the softmax row statistics are then lane-local (one cross-half exchange), and the score tile's
+//     accumulator registers are directly the B operand of the second product (P.V, dS.K, P^T.dO, dS^T.Q)
+//     with no LDS round trip;
+//   * the A operand of those second products needs the streamed tile transposed: it is read from the SAME
+//     row-major LDS image with ds_read_b64_tr_b16.  The image has a 64-byte row pad and a 4-way XOR on the
+//     16-byte chunk index, which makes both the row reads (ds_read_b128) and the transposed reads conflict-free;
+//   * softmax in the exp2 domain with fp32 statistics; fp32 accumulation everywhere.
+// mask_mode 0 = implicit causal, -inf above the diagonal, fully masked key tiles are skipped
+//               (semantics of scaled_upper_triang_masked_softmax.h:143-260);
+// mask_mode 1 = explicit byte mask, 1 -> score := -10000 (semantics of scaled_masked_softmax.h:180-184 and of
+//               the eager gpt2_attention_mask_func path).
 #include "common.h"
-extern "C" int mm_attn_fwd(void*, float*, const void*, const uint8_t*, int, int, int, int, int, int, float, int, void*) {
-    mm::set_error("mm_attn_fwd: not built yet");
-    return MM_EUNSUPPORTED;
+
+namespace mm {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kMaskFill = -10000.0f;
+
+template <typename T> struct M32;
+template <> struct M32<BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag cvt8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+        return frag{(__bf16)a0, (__bf16)a1, (__bf16)a2, (__bf16)a3, (__bf16)a4, (__bf16)a5, (__bf16)a6, (__bf16)a7};
+    }
+};
+template <> struct M32<F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag cvt8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+        return frag{(_Float16)a0, (_Float16)a1, (_Float16)a2, (_Float16)a3, (_Float16)a4, (_Float16)a5, (_Float16)a6, (_Float16)a7};
+    }
+};
+
+// ---- LDS image of a streamed [64 rows][HD] tile
+template <int HD> struct Tile {
+    static constexpr int STRIDE = HD * 2 + 64;        // bytes per row (row pad: 4 tr-read rows cover all 64 banks)
+    static constexpr int BYTES = 64 * STRIDE;
+    static constexpr int CPR = HD / 8;                // 16-byte chunks per row
+    static constexpr int NCH = 64 * CPR / 256;        // chunks per thread per tile
+    static __device__ __forceinline__ int off(int row, int chunk) { return row * STRIDE + ((chunk ^ ((row >> 2) & 3)) << 4); }
+};
+
+template <int HD>
+__device__ __forceinline__ void tile_load(u32x4 (&regs)[Tile<HD>::NCH], const u16* __restrict__ g, size_t row_stride, int row0,
+                                          int nrows, int tid) {
+#pragma unroll
+    for (int i = 0; i < Tile<HD>::NCH; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / Tile<HD>::CPR, ch = c % Tile<HD>::CPR;
+        int gr = row0 + row;
+        gr = gr < nrows ? gr : nrows - 1;
+        regs[i] = *reinterpret_cast<const u32x4*>(g + (size_t)gr * row_stride + ch * 8);
+    }
 }
-extern "C" int mm_attn_bwd(void*, float*, const void*, const void*, const float*, const void*, const uint8_t*, int, int, int, int,
-                           int, int, float, int, void*) {
-    mm::set_error("mm_attn_bwd: not built yet");
-    return MM_EUNSUPPORTED;
+template <int HD>
+__device__ __forceinline__ void tile_store(char* lds, const u32x4 (&regs)[Tile<HD>::NCH], int tid) {
+#pragma unroll
+    for (int i = 0; i < Tile<HD>::NCH; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / Tile<HD>::CPR, ch = c % Tile<HD>::CPR;
+        *reinterpret_cast<u32x4*>(lds + Tile<HD>::off(row, ch)) = regs[i];
+    }
+}
+// A operand, rows = tile rows: lane (r = lane&31, hh = lane>>5) gets tile[row0 + r][16*ds + 8*hh .. +7]
+template <typename T, int HD>
+__device__ __forceinline__ typename M32<T>::frag row_frag(const char* lds, int row0, int ds, int lane) {
+    const int row = row0 + (lane & 31);
+    return *reinterpret_cast<const typename M32<T>::frag*>(lds + Tile<HD>::off(row, 2 * ds + (lane >> 5)));
+}
+// A operand, rows = tile COLUMNS (d = 32*dblk + (lane&31)), k = tile rows in the order the accumulator-as-B-operand
+// uses: element j of lane half hh <-> tile row kb + 8*(j>>2) + 4*hh + (j&3).
+template <typename T, int HD>
+__device__ __forceinline__ typename M32<T>::frag tr_frag(const char* lds, int kb, int dblk, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, hh = lane >> 5;
+    const int col = 32 * dblk + 16 * (g & 1) + 4 * p;
+    const int ra = kb + 4 * hh + q;
+    const int rb = ra + 8;
+    const char* pa = lds + ra * Tile<HD>::STRIDE + ((((col >> 3) ^ ((ra >> 2) & 3))) << 4) + (col & 7) * 2;
+    const char* pb = lds + rb * Tile<HD>::STRIDE + ((((col >> 3) ^ ((rb >> 2) & 3))) << 4) + (col & 7) * 2;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+    const s16x8 v = s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    typename M32<T>::frag f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+
+// row index (within a 32-row score sub-tile) held by accumulator register `reg` of lane half hh
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// mask byte for (q, key); mask row base already selected
+__device__ __forceinline__ bool mask_at(const uint8_t* __restrict__ mrow, int key) { return mrow[key] == 1; }
+
+// =====================================================================================  forward
+template <typename T, int HD, int MODE>
+__global__ __launch_bounds__(256) void attn_fwd_k(u16* __restrict__ ctx, float* __restrict__ lse, const u16* __restrict__ qkv,
+                                                  const uint8_t* __restrict__ mask, int mask_batches, int s, int b, int np,
+                                                  float scale_log2e) {
+    typedef Tile<HD> TL;
+    typedef typename M32<T>::frag frag;
+    constexpr int NDS = HD / 16, NDB = HD / 32;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES];  // [buf][K | V]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int bi = blockIdx.y / np, hi = blockIdx.y % np;
+    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 128;  // heaviest (latest) query blocks first
+    const size_t tok = (size_t)b * np * 3 * HD;                   // elements between sequence positions
+    const u16* qbase = qkv + ((size_t)bi * np + hi) * 3 * HD;
+    const u16* kbase = qbase + HD;
+    const u16* vbase = qbase + 2 * HD;
+
+    const int qrow = q0 + wave * 32 + r;
+    const int qrow_c = qrow < s ? qrow : s - 1;
+    frag qf[NDS];
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) qf[ds] = *reinterpret_cast<const frag*>(qbase + (size_t)qrow_c * tok + 16 * ds + 8 * hh);
+
+    const int blk_last = min(q0 + 127, s - 1);
+    const int ntiles = (MODE == 0) ? (blk_last / 64 + 1) : ((s + 63) / 64);
+    const int wave_last = min(q0 + wave * 32 + 31, s - 1);
+    const uint8_t* mrow = nullptr;
+    if (MODE == 1) mrow = mask + ((size_t)(mask_batches == 1 ? 0 : bi) * s + qrow_c) * s;
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    u32x4 kreg[TL::NCH], vreg[TL::NCH];
+    tile_load<HD>(kreg, kbase, tok, 0, s, tid);
+    tile_load<HD>(vreg, vbase, tok, 0, s, tid);
+    tile_store<HD>(smem, kreg, tid);
+    tile_store<HD>(smem + TL::BYTES, vreg, tid);
+    __syncthreads();
+
+    for (int j = 0; j < ntiles; ++j) {
+        const int cur = j & 1;
+        const char* ks = smem + cur * 2 * TL::BYTES;
+        const char* vs = ks + TL::BYTES;
+        if (j + 1 < ntiles) {
+            tile_load<HD>(kreg, kbase, tok, (j + 1) * 64, s, tid);
+            tile_load<HD>(vreg, vbase, tok, (j + 1) * 64, s, tid);
+        }
+        const int kv0 = j * 64;
+        if (MODE == 1 || kv0 <= wave_last) {  // wave-uniform: skip key tiles entirely above this wave's diagonal
+            f32x16 sacc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
+#pragma unroll
+                for (int ds = 0; ds < NDS; ++ds) sacc[t] = M32<T>::run(row_frag<T, HD>(ks, 32 * t, ds, lane), qf[ds], sacc[t]);
+            }
+            float rmax = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + 32 * t + acc_row(i, hh);
+                    float v = sacc[t][i] * scale_log2e;
+                    if (MODE == 0) {
+                        if (key > qrow) v = -INFINITY;
+                    } else {
+                        if (key >= s) v = -INFINITY;
+                        else if (mask_at(mrow, key)) v = kMaskFill * kLog2e;
+                    }
+                    sacc[t][i] = v;
+                    rmax = fmaxf(rmax, v);
+                }
+            rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+            const float m_new = fmaxf(m_run, rmax);
+            const float alpha = fast_exp2(m_run - m_new);
+            float lsum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = fast_exp2(sacc[t][i] - m_new);
+                    sacc[t][i] = p;
+                    lsum += p;
+                }
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const frag pf = M32<T>::cvt8(sacc[t][8 * s2], sacc[t][8 * s2 + 1], sacc[t][8 * s2 + 2], sacc[t][8 * s2 + 3],
+                                                 sacc[t][8 * s2 + 4], sacc[t][8 * s2 + 5], sacc[t][8 * s2 + 6], sacc[t][8 * s2 + 7]);
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) o[d] = M32<T>::run(tr_frag<T, HD>(vs, 32 * t + 16 * s2, d, lane), pf, o[d]);
+                }
+        }
+        if (j + 1 < ntiles) {
+            char* nk = smem + (cur ^ 1) * 2 * TL::BYTES;
+            tile_store<HD>(nk, kreg, tid);
+            tile_store<HD>(nk + TL::BYTES, vreg, tid);
+        }
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < s) {
+        u16* orow = ctx + ((size_t)qrow * b + bi) * ((size_t)np * HD) + (size_t)hi * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = 32 * d + 8 * g4 + 4 * hh;
+                const u16 a0 = from_f32<T>(o[d][4 * g4] * inv), a1 = from_f32<T>(o[d][4 * g4 + 1] * inv);
+                const u16 a2 = from_f32<T>(o[d][4 * g4 + 2] * inv), a3 = from_f32<T>(o[d][4 * g4 + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + d0) = u32x2{(uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16)};
+            }
+        if (hh == 0) lse[((size_t)bi * np + hi) * s + qrow] = (m_run + __log2f(l_tot)) * kLn2;
+    }
+}
+
+// =====================================================================================  backward: delta
+// delta[b, np, s] = sum_d dO[q][d] * O[q][d]
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_delta_k(float* __restrict__ delta, const u16* __restrict__ dctx,
+                                                    const u16* __restrict__ ctx, int s, int b, int np) {
+    constexpr int LPR = HD / 8;  // lanes per row
+    const size_t nrows = (size_t)s * b * np;
+    const size_t row = ((size_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int c = threadIdx.x % LPR;
+    float acc = 0.f;
+    if (row < nrows) {
+        float a[8], o[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(dctx + row * HD + c * 8), a);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(ctx + row * HD + c * 8), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (row < nrows && c == 0) {
+        const size_t si = row / ((size_t)b * np);
+        const size_t rem = row % ((size_t)b * np);
+        delta[rem * s + si] = acc;  // rem = bi*np + hi
+    }
+}
+
+// =====================================================================================  backward: dQ
+template <typename T, int HD, int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_dq_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
+                                                     const float* __restrict__ lse, const float* __restrict__ delta,
+                                                     const u16* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                     int mask_batches, int s, int b, int np, float scale_log2e, float scale) {
+    typedef Tile<HD> TL;
+    typedef typename M32<T>::frag frag;
+    constexpr int NDS = HD / 16, NDB = HD / 32;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int bi = blockIdx.y / np, hi = blockIdx.y % np;
+    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 128;
+    const size_t tok = (size_t)b * np * 3 * HD;
+    const u16* qbase = qkv + ((size_t)bi * np + hi) * 3 * HD;
+    const u16* kbase = qbase + HD;
+    const u16* vbase = qbase + 2 * HD;
+
+    const int qrow = q0 + wave * 32 + r;
+    const int qrow_c = qrow < s ? qrow : s - 1;
+    frag qf[NDS], dof[NDS];
+    const u16* dorow = dctx + ((size_t)qrow_c * b + bi) * ((size_t)np * HD) + (size_t)hi * HD;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+        qf[ds] = *reinterpret_cast<const frag*>(qbase + (size_t)qrow_c * tok + 16 * ds + 8 * hh);
+        dof[ds] = *reinterpret_cast<const frag*>(dorow + 16 * ds + 8 * hh);
+    }
+    const float lse2 = lse[((size_t)bi * np + hi) * s + qrow_c] * kLog2e;
+    const float dlt = delta[((size_t)bi * np + hi) * s + qrow_c];
+
+    const int blk_last = min(q0 + 127, s - 1);
+    const int ntiles = (MODE == 0) ? (blk_last / 64 + 1) : ((s + 63) / 64);
+    const int wave_last = min(q0 + wave * 32 + 31, s - 1);
+    const uint8_t* mrow = nullptr;
+    if (MODE == 1) mrow = mask + ((size_t)(mask_batches == 1 ? 0 : bi) * s + qrow_c) * s;
+
+    f32x16 dq[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dq[i][j] = 0.f;
+
+    u32x4 kreg[TL::NCH], vreg[TL::NCH];
+    tile_load<HD>(kreg, kbase, tok, 0, s, tid);
+    tile_load<HD>(vreg, vbase, tok, 0, s, tid);
+    tile_store<HD>(smem, kreg, tid);
+    tile_store<HD>(smem + TL::BYTES, vreg, tid);
+    __syncthreads();
+
+    for (int j = 0; j < ntiles; ++j) {
+        const int cur = j & 1;
+        const char* ks = smem + cur * 2 * TL::BYTES;
+        const char* vs = ks + TL::BYTES;
+        if (j + 1 < ntiles) {
+            tile_load<HD>(kreg, kbase, tok, (j + 1) * 64, s, tid);
+            tile_load<HD>(vreg, vbase, tok, (j + 1) * 64, s, tid);
+        }
+        const int kv0 = j * 64;
+        if (MODE == 1 || kv0 <= wave_last) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 sacc, dpacc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[i] = dpacc[i] = 0.f;
+#pragma unroll
+                for (int ds = 0; ds < NDS; ++ds) {
+                    sacc = M32<T>::run(row_frag<T, HD>(ks, 32 * t, ds, lane), qf[ds], sacc);
+                    dpacc = M32<T>::run(row_frag<T, HD>(vs, 32 * t, ds, lane), dof[ds], dpacc);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + 32 * t + acc_row(i, hh);
+                    float p, live = 1.f;
+                    if (MODE == 0) {
+                        p = (key > qrow) ? 0.f : fast_exp2(sacc[i] * scale_log2e - lse2);
+                    } else {
+                        const bool dead = key >= s;
+                        const bool mk = !dead && mask_at(mrow, key);
+                        p = dead ? 0.f : fast_exp2((mk ? kMaskFill * kLog2e : sacc[i] * scale_log2e) - lse2);
+                        live = mk ? 0.f : 1.f;  // a masked score is the constant -10000: no gradient flows into q.k
+                    }
+                    sacc[i] = p * (dpacc[i] - dlt) * scale * live;  // dS (w.r.t. the raw q.k product)
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const frag dsf = M32<T>::cvt8(sacc[8 * s2], sacc[8 * s2 + 1], sacc[8 * s2 + 2], sacc[8 * s2 + 3],
+                                                  sacc[8 * s2 + 4], sacc[8 * s2 + 5], sacc[8 * s2 + 6], sacc[8 * s2 + 7]);
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) dq[d] = M32<T>::run(tr_frag<T, HD>(ks, 32 * t + 16 * s2, d, lane), dsf, dq[d]);
+                }
+            }
+        }
+        if (j + 1 < ntiles) {
+            char* nk = smem + (cur ^ 1) * 2 * TL::BYTES;
+            tile_store<HD>(nk, kreg, tid);
+            tile_store<HD>(nk + TL::BYTES, vreg, tid);
+        }
+        __syncthreads();
+    }
+    if (qrow < s) {
+        u16* orow = dqkv + (size_t)qrow * tok + ((size_t)bi * np + hi) * 3 * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = 32 * d + 8 * g4 + 4 * hh;
+                const u16 a0 = from_f32<T>(dq[d][4 * g4]), a1 = from_f32<T>(dq[d][4 * g4 + 1]);
+                const u16 a2 = from_f32<T>(dq[d][4 * g4 + 2]), a3 = from_f32<T>(dq[d][4 * g4 + 3]);
+                *reinterpret_cast<u32x2*>(orow + d0) = u32x2{(uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16)};
+            }
+    }
+}
+
+// =====================================================================================  backward: dK, dV
+template <typename T, int HD, int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
+                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                      const u16* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                      int mask_batches, int s, int b, int np, float scale_log2e, float scale) {
+    typedef Tile<HD> TL;
+    typedef typename M32<T>::frag frag;
+    constexpr int NDS = HD / 16, NDB = HD / 32;
+    // [buf][Q | dO] tiles, then [buf][lse2[64] | delta[64]] floats
+    __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES + 2 * 2 * 64 * 4];
+    float* stat = reinterpret_cast<float*>(smem + 4 * TL::BYTES);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int bi = blockIdx.y / np, hi = blockIdx.y % np;
+    const int k0 = blockIdx.x * 128;  // early key blocks see the most queries: they come first
+    const size_t tok = (size_t)b * np * 3 * HD;
+    const size_t ctok = (size_t)b * np * HD;
+    const u16* qbase = qkv + ((size_t)bi * np + hi) * 3 * HD;
+    const u16* kbase = qbase + HD;
+    const u16* vbase = qbase + 2 * HD;
+    const u16* dobase = dctx + (size_t)bi * np * HD + (size_t)hi * HD;
+    const float* lse_bh = lse + ((size_t)bi * np + hi) * s;
+    const float* dlt_bh = delta + ((size_t)bi * np + hi) * s;
+
+    const int krow = k0 + wave * 32 + r;
+    const int krow_c = krow < s ? krow : s - 1;
+    frag kf[NDS], vf[NDS];
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+        kf[ds] = *reinterpret_cast<const frag*>(kbase + (size_t)krow_c * tok + 16 * ds + 8 * hh);
+        vf[ds] = *reinterpret_cast<const frag*>(vbase + (size_t)krow_c * tok + 16 * ds + 8 * hh);
+    }
+    const int nqt = (s + 63) / 64;
+    const int jt0 = (MODE == 0) ? (k0 / 64) : 0;
+    const int wave_first = k0 + wave * 32;  // smallest key of this wave
+    const uint8_t* mbase = nullptr;
+    if (MODE == 1) mbase = mask + (size_t)(mask_batches == 1 ? 0 : bi) * s * s;
+
+    f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dk[i][j] = dv[i][j] = 0.f;
+
+    u32x4 qreg[TL::NCH], oreg[TL::NCH];
+    float st_l = 0.f, st_d = 0.f;
+    auto load_stats = [&](int row0) {
+        if (tid < 64) {
+            int q = row0 + tid;
+            q = q < s ? q : s - 1;
+            st_l = lse_bh[q] * kLog2e;
+            st_d = dlt_bh[q];
+        }
+    };
+    auto store_stats = [&](int buf) {
+        if (tid < 64) {
+            stat[buf * 128 + tid] = st_l;
+            stat[buf * 128 + 64 + tid] = st_d;
+        }
+    };
+    tile_load<HD>(qreg, qbase, tok, jt0 * 64, s, tid);
+    tile_load<HD>(oreg, dobase, ctok, jt0 * 64, s, tid);
+    load_stats(jt0 * 64);
+    tile_store<HD>(smem, qreg, tid);
+    tile_store<HD>(smem + TL::BYTES, oreg, tid);
+    store_stats(0);
+    __syncthreads();
+
+    for (int j = jt0; j < nqt; ++j) {
+        const int cur = (j - jt0) & 1;
+        const char* qs = smem + cur * 2 * TL::BYTES;
+        const char* os = qs + TL::BYTES;
+        const float* sl = stat + cur * 128;
+        if (j + 1 < nqt) {
+            tile_load<HD>(qreg, qbase, tok, (j + 1) * 64, s, tid);
+            tile_load<HD>(oreg, dobase, ctok, (j + 1) * 64, s, tid);
+            load_stats((j + 1) * 64);
+        }
+        const int q0t = j * 64;
+        if (MODE == 1 || q0t + 63 >= wave_first) {  // some query of the tile can see a key of this wave
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 sacc, dpacc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[i] = dpacc[i] = 0.f;
+#pragma unroll
+                for (int ds = 0; ds < NDS; ++ds) {
+                    sacc = M32<T>::run(row_frag<T, HD>(qs, 32 * t, ds, lane), kf[ds], sacc);    // S[q][key]
+                    dpacc = M32<T>::run(row_frag<T, HD>(os, 32 * t, ds, lane), vf[ds], dpacc);  // dP[q][key]
+                }
+                float pv[16];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int ql = 32 * t + 8 * g4 + 4 * hh;  // local row of register 4*g4
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + ql);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sl + 64 + ql);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * g4 + e;
+                        const int q = q0t + ql + e;
+                        float p, live = 1.f;
+                        if (MODE == 0) {
+                            p = (krow > q || q >= s) ? 0.f : fast_exp2(sacc[i] * scale_log2e - l4[e]);
+                        } else {
+                            const bool dead = (q >= s) || (krow >= s);
+                            const bool mk = !dead && mask_at(mbase + (size_t)q * s, krow);
+                            p = dead ? 0.f : fast_exp2((mk ? kMaskFill * kLog2e : sacc[i] * scale_log2e) - l4[e]);
+                            live = mk ? 0.f : 1.f;
+                        }
+                        pv[i] = p;
+                        sacc[i] = p * (dpacc[i] - d4[e]) * scale * live;  // dS[q][key]
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const frag pf = M32<T>::cvt8(pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3], pv[8 * s2 + 4],
+                                                 pv[8 * s2 + 5], pv[8 * s2 + 6], pv[8 * s2 + 7]);
+                    const frag dsf = M32<T>::cvt8(sacc[8 * s2], sacc[8 * s2 + 1], sacc[8 * s2 + 2], sacc[8 * s2 + 3],
+                                                  sacc[8 * s2 + 4], sacc[8 * s2 + 5], sacc[8 * s2 + 6], sacc[8 * s2 + 7]);
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) {
+                        dv[d] = M32<T>::run(tr_frag<T, HD>(os, 32 * t + 16 * s2, d, lane), pf, dv[d]);   // dV^T += dO^T . P
+                        dk[d] = M32<T>::run(tr_frag<T, HD>(qs, 32 * t + 16 * s2, d, lane), dsf, dk[d]);  // dK^T += Q^T . dS
+                    }
+                }
+            }
+        }
+        if (j + 1 < nqt) {
+            char* nq = smem + (cur ^ 1) * 2 * TL::BYTES;
+            tile_store<HD>(nq, qreg, tid);
+            tile_store<HD>(nq + TL::BYTES, oreg, tid);
+            store_stats(cur ^ 1);
+        }
+        __syncthreads();
+    }
+    if (krow < s) {
+        u16* krow_o = dqkv + (size_t)krow * tok + ((size_t)bi * np + hi) * 3 * HD + HD;
+        u16* vrow_o = krow_o + HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = 32 * d + 8 * g4 + 4 * hh;
+                u16 a0 = from_f32<T>(dk[d][4 * g4]), a1 = from_f32<T>(dk[d][4 * g4 + 1]);
+                u16 a2 = from_f32<T>(dk[d][4 * g4 + 2]), a3 = from_f32<T>(dk[d][4 * g4 + 3]);
+                *reinterpret_cast<u32x2*>(krow_o + d0) = u32x2{(uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16)};
+                a0 = from_f32<T>(dv[d][4 * g4]); a1 = from_f32<T>(dv[d][4 * g4 + 1]);
+                a2 = from_f32<T>(dv[d][4 * g4 + 2]); a3 = from_f32<T>(dv[d][4 * g4 + 3]);
+                *reinterpret_cast<u32x2*>(vrow_o + d0) = u32x2{(uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16)};
+            }
+    }
+}
+
+template <typename T, int HD>
+static int launch_fwd(void* ctx, float* lse, const void* qkv, const uint8_t* mask, int mode, int mb, int s, int b, int np,
+                      float scale, hipStream_t st) {
+    dim3 grid((s + 127) / 128, b * np), block(256);
+    const float sl2 = scale * kLog2e;
+    if (mode == 0)
+        attn_fwd_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)ctx, lse, (const u16*)qkv, nullptr, 1, s, b, np, sl2);
+    else
+        attn_fwd_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)ctx, lse, (const u16*)qkv, mask, mb, s, b, np, sl2);
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
+template <typename T, int HD>
+static int launch_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
+                      const uint8_t* mask, int mode, int mb, int s, int b, int np, float scale, hipStream_t st) {
+    const size_t nrows = (size_t)s * b * np;
+    const size_t nthreads = nrows * (HD / 8);
+    attn_delta_k<T, HD><<<(unsigned)((nthreads + 255) / 256), 256, 0, st>>>(delta, (const u16*)dctx, (const u16*)ctx, s, b, np);
+    MM_CHECK_LAUNCH();
+    dim3 grid((s + 127) / 128, b * np), block(256);
+    const float sl2 = scale * kLog2e;
+    if (mode == 0) {
+        attn_bwd_dkv_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale);
+        MM_CHECK_LAUNCH();
+        attn_bwd_dq_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale);
+    } else {
+        attn_bwd_dkv_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale);
+        MM_CHECK_LAUNCH();
+        attn_bwd_dq_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale);
+    }
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
+static int check_common(const char* fn, int mask_mode, const uint8_t* mask, int mask_batches, int s, int b, int np, int hn) {
+    MM_CHECK_ARG(s > 0 && b > 0 && np > 0, "%s: s=%d b=%d np=%d must be positive", fn, s, b, np);
+    MM_CHECK_ARG(hn == 64 || hn == 128, "%s: head size %d not supported (64 or 128)", fn, hn);
+    MM_CHECK_ARG(mask_mode == 0 || mask_mode == 1, "%s: mask_mode must be 0 (causal) or 1 (byte mask)", fn);
+    if (mask_mode == 1) {
+        MM_CHECK_ARG(mask != nullptr, "%s: mask_mode 1 needs a mask", fn);
+        MM_CHECK_ARG(mask_batches == 1 || mask_batches == b, "%s: mask batch %d must be 1 or %d", fn, mask_batches, b);
+    }
+    MM_CHECK_ARG((long long)b * np <= 65535, "%s: b*np=%lld exceeds the grid limit", fn, (long long)b * np);
+    return MM_OK;
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" int mm_attn_fwd(void* ctx, float* lse, const void* qkv, const uint8_t* mask, int mask_mode, int mask_batches, int s,
+                           int b, int np, int hn, float softmax_scale, int dtype, void* stream) {
+    MM_CHECK_ARG(ctx && lse && qkv, "mm_attn_fwd: null pointer");
+    if (int rc = check_common("mm_attn_fwd", mask_mode, mask, mask_batches, s, b, np, hn)) return rc;
+    MM_CHECK_ARG(aligned16(qkv) && aligned16(ctx), "mm_attn_fwd: qkv/ctx must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        if (hn == 64) return launch_fwd<T, 64>(ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale, st);
+        return launch_fwd<T, 128>(ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale, st);
+    });
+}
+
+extern "C" int mm_attn_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
+                           const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn,
+                           float softmax_scale, int dtype, void* stream) {
+    MM_CHECK_ARG(dqkv && delta && dctx && ctx && lse && qkv, "mm_attn_bwd: null pointer");
+    if (int rc = check_common("mm_attn_bwd", mask_mode, mask, mask_batches, s, b, np, hn)) return rc;
+    MM_CHECK_ARG(aligned16(qkv) && aligned16(ctx) && aligned16(dctx) && aligned16(dqkv), "mm_attn_bwd: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        if (hn == 64) return launch_bwd<T, 64>(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale, st);
+        return launch_bwd<T, 128>(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale, st);
+    });
 }

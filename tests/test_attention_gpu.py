@@ -1,0 +1,118 @@
+"""GPU parity of the fused attention kernels (C ABI mm_attn_fwd / mm_attn_bwd) against an fp32 CPU restatement of
+ParallelSelfAttention.attention (megatron/model/transformer.py:315-416) on the same 16-bit inputs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def ref_attention(qkv, s, b, np_, hn, scale, mask, causal_inf):
+    """fp32 reference on the rounded inputs.  qkv: [s,b,np,3hn].  Returns ctx [s,b,np*hn], lse [b,np,s]."""
+    q, k, v = qkv.float().split(hn, dim=-1)
+    scores = torch.einsum("sbnd,tbnd->bnst", q, k) * scale
+    if causal_inf:
+        dead = torch.triu(torch.ones(s, s, dtype=torch.bool), 1)
+        scores = scores.masked_fill(dead, float("-inf"))
+    else:
+        scores = torch.where(mask.expand(b, np_, s, s), torch.full_like(scores, -10000.0), scores)
+    lse = torch.logsumexp(scores, dim=-1)
+    p = torch.softmax(scores, dim=-1)
+    ctx = torch.einsum("bnst,tbnd->sbnd", p, v).reshape(s, b, np_ * hn)
+    return ctx, lse
+
+
+def run_case(dev, dt, s, b, np_, hn, mode, seed=0):
+    from multimodal_amd import ops
+    torch.manual_seed(seed)
+    dtype = DT[dt]
+    qkv = torch.randn(s, b, np_, 3 * hn).to(dtype)
+    dctx = torch.randn(s, b, np_ * hn).to(dtype)
+    scale = 1.0 / math.sqrt(hn)
+    mask = None
+    if mode == "causal_bytes":
+        mask = torch.triu(torch.ones(s, s, dtype=torch.bool), 1).view(1, 1, s, s)
+    elif mode == "general":
+        mask = torch.rand(b, 1, s, s) < 0.4
+        mask[:, :, 3, :] = True      # a fully masked row -> uniform attention over all keys (reference -10000 semantics)
+        mask[:, :, 5, :] = False
+    x = qkv.clone().requires_grad_(True)
+    ctx_ref, lse_ref = ref_attention(x, s, b, np_, hn, scale, mask, causal_inf=(mode == "causal"))
+    ctx_ref.backward(dctx.float())
+    dqkv_ref = x.grad
+
+    g_qkv = qkv.to(dev)
+    g_mask = mask.to(dev) if mask is not None else None
+    ctx, lse = ops.attn_fwd(g_qkv, s, b, np_, hn, scale, g_mask)
+    dqkv = ops.attn_bwd(dctx.to(dev), ctx, lse, g_qkv, s, b, np_, hn, scale, g_mask)
+    torch.cuda.synchronize()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    # forward: P is rounded to 16 bit before P.V -> error ~ eps * sum|p v| <= eps * max|v|
+    err = (ctx.float().cpu() - ctx_ref.detach()).abs().max().item()
+    assert err <= 4 * eps * qkv.float().abs().max().item(), f"ctx max err {err}"
+    lerr = (lse.cpu() - lse_ref.detach()).abs().max().item()
+    assert lerr <= 2e-3, f"lse max err {lerr}"
+    gerr = (dqkv.float().cpu() - dqkv_ref).abs().max().item()
+    gscale = dqkv_ref.abs().max().item()
+    assert gerr <= 6 * eps * gscale + 1e-3, f"dqkv max err {gerr} (scale {gscale})"
+    # relative L2 per slice is a much sharper check for systematic (permutation / sign) errors
+    for name, sl in (("dq", slice(0, hn)), ("dk", slice(hn, 2 * hn)), ("dv", slice(2 * hn, 3 * hn))):
+        a, r = dqkv.float().cpu()[..., sl], dqkv_ref[..., sl]
+        rel = ((a - r).norm() / r.norm().clamp_min(1e-6)).item()
+        assert rel <= 3 * eps, f"{name} relative L2 error {rel}"
+    rel = ((ctx.float().cpu() - ctx_ref.detach()).norm() / ctx_ref.detach().norm()).item()
+    assert rel <= 2 * eps, f"ctx relative L2 error {rel}"
+    return ctx, dqkv
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("hn", [64, 128])
+@pytest.mark.parametrize("s", [64, 128, 200, 512])
+@pytest.mark.parametrize("mode", ["causal", "causal_bytes", "general"])
+def test_attention_fwd_bwd(cuda_device, dt, hn, s, mode):
+    run_case(cuda_device, dt, s, 2, 3, hn, mode, seed=s + hn)
+
+
+def test_attention_causal_equals_byte_mask(cuda_device):
+    """Implicit causal (-inf) and the same mask given as bytes (-10000) agree: exp(-10000 - m) == 0 in fp32."""
+    from multimodal_amd import ops
+    torch.manual_seed(1)
+    s, b, np_, hn = 256, 1, 4, 64
+    qkv = torch.randn(s, b, np_, 3 * hn).bfloat16().to(cuda_device)
+    mask = torch.triu(torch.ones(s, s, dtype=torch.bool), 1).view(1, 1, s, s).to(cuda_device)
+    c1, l1 = ops.attn_fwd(qkv, s, b, np_, hn, 0.125, None)
+    c2, l2 = ops.attn_fwd(qkv, s, b, np_, hn, 0.125, mask)
+    assert torch.equal(c1, c2) and torch.allclose(l1, l2, atol=1e-6)
+
+
+def test_attention_410m_shape_properties(cuda_device):
+    """BASELINE size (s=2048, b=4, np=16, hn=64): too big for the CPU reference in seconds, so check size-independent
+    properties: (1) V = const -> ctx = const; (2) linearity in V; (3) row 0 attends to key 0 only; (4) sum_d dV check."""
+    from multimodal_amd import ops
+    torch.manual_seed(2)
+    s, b, np_, hn = 2048, 4, 16, 64
+    qkv = torch.randn(s, b, np_, 3 * hn, device=cuda_device).bfloat16()
+    ctx, lse = ops.attn_fwd(qkv, s, b, np_, hn, 0.125, None)
+    v = qkv[..., 2 * hn:]
+    assert torch.equal(ctx[0].view(b, np_, hn), v[0]), "query 0 sees only key 0"
+    q2 = qkv.clone()
+    q2[..., 2 * hn:] = 1.0
+    c_const, _ = ops.attn_fwd(q2, s, b, np_, hn, 0.125, None)
+    assert (c_const.float() - 1.0).abs().max() <= 2 ** -7
+    q3 = qkv.clone()
+    q3[..., 2 * hn:] = v * 2
+    c_dbl, l_dbl = ops.attn_fwd(q3, s, b, np_, hn, 0.125, None)
+    assert torch.equal(c_dbl.float(), ctx.float() * 2) and torch.equal(l_dbl, lse)
+    # backward: with dctx = const c, dV[t] = c * sum_q P[q,t]; summed over keys per (b, head) that is c * s
+    dctx = torch.ones(s, b, np_ * hn, device=cuda_device).bfloat16()
+    dqkv = ops.attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, 0.125, None)
+    dv = dqkv[..., 2 * hn:].float()
+    tot = dv.sum(dim=0)  # [b, np, hn]
+    assert (tot / s - 1.0).abs().max() <= 2e-2
+    # dq and dk: rows of P sum to one -> dP - delta has zero P-weighted mean -> sum over keys of dS is 0 -> no check on values,
+    # but both must be finite and non-trivial
+    assert torch.isfinite(dqkv.float()).all()
+    assert dqkv[..., :hn].float().abs().max() < 1e-2  # dO.V^T constant across keys => dS = 0 => dq = dk = 0 (up to rounding)
