@@ -102,6 +102,14 @@ int mm_transpose2d(void* out, const void* in, int rows, int cols, void* stream);
 /* elementwise out = a + b (+ c), n elements. */
 int mm_add(void* out, const void* a, const void* b, const void* c, size_t n, int dtype, void* stream);
 
+/* dx = act > 0 ? g : 0 - backward of the adapter's nn.ReLU (megatron/model/adapter.py:18-24); n elements. */
+int mm_relu_bwd(void* dx, const void* g, const void* act, size_t n, int dtype, void* stream);
+/* The GPT-J residual tail (megatron/model/transformer.py:747-766) in one pass:
+ * out = [x +] ((attn + attn_bias) + (mlp + mlp_bias)), every intermediate rounded to `dtype` like the eager
+ * bias_dropout_add ops (p = 0).  x == NULL leaves the residual add to the caller (TP > 1: the all-reduce sits between). */
+int mm_gptj_combine(void* out, const void* x, const void* attn, const void* attn_bias, const void* mlp,
+                    const void* mlp_bias, int rows, int cols, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ GEMM (MFMA)
  * Replaces F.linear in ColumnParallelLinear / RowParallelLinear (megatron/mpu/layers.py:557,745):
  *   C[M, N] = A[M, K] * B[N, K]^T  (+ bias[N]) (+ epilogue), fp32 accumulate, output in `dtype`.

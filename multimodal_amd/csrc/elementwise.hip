@@ -337,3 +337,76 @@ extern "C" int mm_add(void* out, const void* a, const void* b, const void* c, si
         return (int)MM_OK;
     });
 }
+
+// ------------------------------------------------------------------------------------ relu backward / gpt-j combine
+namespace mm {
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_k(u16* __restrict__ dx, const u16* __restrict__ g, const u16* __restrict__ act, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 gr = *reinterpret_cast<const u32x4*>(g + i * 8);
+        const u32x4 ar = *reinterpret_cast<const u32x4*>(act + i * 8);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // act is a ReLU output (>= 0): "positive" <=> non-zero magnitude bits and sign clear
+            const uint32_t lo = ((ar[j] & 0x7fffu) != 0 && (ar[j] & 0x8000u) == 0) ? (gr[j] & 0xffffu) : 0u;
+            const uint32_t hi = ((ar[j] & 0x7fff0000u) != 0 && (ar[j] & 0x80000000u) == 0) ? (gr[j] & 0xffff0000u) : 0u;
+            o[j] = lo | hi;
+        }
+        *reinterpret_cast<u32x4*>(dx + i * 8) = o;
+    }
+}
+
+// GPT-J residual tail at TP = 1 (reference transformer.py:747-766), one pass:
+//   t1 = attn + b_a ; t2 = mlp + b_m ; t3 = t1 + t2 ; out = x + t3, each rounded to T like the eager ops.
+template <typename T>
+__global__ __launch_bounds__(256) void gptj_combine_k(u16* __restrict__ out, const u16* __restrict__ x, const u16* __restrict__ attn,
+                                                      const u16* __restrict__ ba, const u16* __restrict__ mlp,
+                                                      const u16* __restrict__ bm, size_t rows, int cols, int add_x) {
+    const int cpr = cols >> 3;
+    const size_t total = rows * cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr);
+        float xv[8], av[8], mv[8], b1[8], b2[8], o[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(attn + i * 8), av);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(mlp + i * 8), mv);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(ba + c * 8), b1);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(bm + c * 8), b2);
+        if (add_x) unpack8<T>(*reinterpret_cast<const u32x4*>(x + i * 8), xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t3 = rnd<T>(rnd<T>(av[j] + b1[j]) + rnd<T>(mv[j] + b2[j]));
+            o[j] = add_x ? xv[j] + t3 : t3;
+        }
+        *reinterpret_cast<u32x4*>(out + i * 8) = pack8<T>(o);
+    }
+}
+}  // namespace mm
+
+extern "C" int mm_relu_bwd(void* dx, const void* g, const void* act, size_t n, int dtype, void* stream) {
+    MM_CHECK_ARG(dx && g && act, "mm_relu_bwd: null pointer");
+    MM_CHECK_ARG(n > 0 && n % 8 == 0, "mm_relu_bwd: n must be a positive multiple of 8");
+    MM_CHECK_ARG(aligned16(dx) && aligned16(g) && aligned16(act), "mm_relu_bwd: pointers must be 16-byte aligned");
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        relu_bwd_k<T><<<grid_for(n / 8), 256, 0, (hipStream_t)stream>>>((u16*)dx, (const u16*)g, (const u16*)act, n / 8);
+        MM_CHECK_LAUNCH();
+        return (int)MM_OK;
+    });
+}
+
+extern "C" int mm_gptj_combine(void* out, const void* x, const void* attn, const void* attn_bias, const void* mlp,
+                               const void* mlp_bias, int rows, int cols, int dtype, void* stream) {
+    MM_CHECK_ARG(out && attn && attn_bias && mlp && mlp_bias, "mm_gptj_combine: null pointer");
+    MM_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0, "mm_gptj_combine: rows=%d cols=%d (cols must be a multiple of 8)", rows, cols);
+    MM_CHECK_ARG(aligned16(out) && aligned16(attn) && aligned16(mlp) && aligned16(attn_bias) && aligned16(mlp_bias) && (!x || aligned16(x)),
+                 "mm_gptj_combine: pointers must be 16-byte aligned");
+    const size_t items = (size_t)rows * (cols / 8);
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        gptj_combine_k<T><<<grid_for(items), 256, 0, (hipStream_t)stream>>>((u16*)out, (const u16*)x, (const u16*)attn, (const u16*)attn_bias,
+                                                                           (const u16*)mlp, (const u16*)mlp_bias, rows, cols, x ? 1 : 0);
+        MM_CHECK_LAUNCH();
+        return (int)MM_OK;
+    });
+}

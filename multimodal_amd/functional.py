@@ -1,0 +1,266 @@
+"""Autograd wiring of the HIP kernels: each Function's forward AND backward are C-ABI kernel launches
+(``multimodal_amd.ops``); torch.autograd only sequences them.
+
+Memory policy (MI355X, 288 GB HBM3E): the transposed copy W^T that the data-gradient GEMM wants as its
+K-contiguous operand is cached per weight (refreshed when the weight's version counter moves), so a frozen
+language model (reference `freeze_lm`, megatron/training.py:454-459) pays for the transposes once.
+"""
+import torch
+
+from . import _lib, ops
+
+_WT_CACHE = {}  # id(weight) -> (data_ptr, version, W^T)
+
+
+def weight_t(w):
+    """Cached contiguous W^T ([in, out]) of a [out, in] weight."""
+    key = id(w)
+    ent = _WT_CACHE.get(key)
+    if ent is not None and ent[0] == w.data_ptr() and ent[1] == w._version and ent[2].device == w.device:
+        return ent[2]
+    wt = ops.transpose2d(w.detach())
+    _WT_CACHE[key] = (w.data_ptr(), w._version, wt)
+    return wt
+
+
+def clear_weight_cache():
+    _WT_CACHE.clear()
+
+
+def _flat2d(t):
+    return t.reshape(-1, t.size(-1))
+
+
+def _wgrad(dy2d, x2d):
+    """dW[N, K] = dY^T[N, M] . X[M, K]  (contraction over the token dimension)."""
+    return ops.gemm_nt(ops.transpose2d(dy2d), ops.transpose2d(x2d))
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ bias) (+ residual): F.linear of the reference's Column/Row linears (mpu/layers.py:557,745)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        return ops.gemm_nt(x, weight, bias, _lib.EPI_BIAS if bias is not None else _lib.EPI_NONE, residual=residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dy2 = _flat2d(dy)
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(dy2, weight_t(weight)).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(dy2, _flat2d(x))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2)
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres
+
+
+def linear(x, weight, bias=None, residual=None):
+    return LinearFn.apply(x, weight, bias, residual)
+
+
+class LinearBiasGeluFn(torch.autograd.Function):
+    """act = gelu(x W^T + bias) with the activation fused into the GEMM epilogue.
+    mode 0: tanh approximation = bias_gelu_impl (megatron/model/activations.py:62-96);
+    mode 1: exact erf = F.gelu(y + bias) (megatron/model/transformer.py:127-130).
+    The rounded pre-bias product is kept for the backward, as the reference's GeLUFunction saves it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mode):
+        act, pre = ops.gemm_nt(x, weight, bias, _lib.EPI_BIAS_GELU_TANH if mode == 0 else _lib.EPI_BIAS_GELU_ERF)
+        ctx.save_for_backward(x, weight, bias, pre)
+        ctx.mode = mode
+        return act
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias, pre = ctx.saved_tensors
+        dpre = ops.bias_gelu_bwd(g.contiguous(), pre, bias, ctx.mode)
+        d2 = _flat2d(dpre)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(d2, weight_t(weight)).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(d2, _flat2d(x))
+        if ctx.needs_input_grad[2]:
+            db = ops.colsum(d2)
+        return dx, dw, db, None
+
+
+def linear_bias_gelu(x, weight, bias, mode):
+    return LinearBiasGeluFn.apply(x, weight, bias, mode)
+
+
+class AdapterFn(torch.autograd.Function):
+    """o' = o + W2 relu(W1 o + b1) + b2 - the bottleneck adapter of AdapterWrapper
+    (megatron/model/adapter.py:18-25,109-117) as two GEMMs with fused bias/ReLU/residual epilogues."""
+
+    @staticmethod
+    def forward(ctx, o, w1, b1, w2, b2):
+        h1 = ops.gemm_nt(o, w1, b1, _lib.EPI_BIAS_RELU)
+        out = ops.gemm_nt(h1, w2, b2, _lib.EPI_BIAS, residual=o)
+        ctx.save_for_backward(o, w1, w2, h1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        o, w1, w2, h1 = ctx.saved_tensors
+        g = g.contiguous()
+        g2 = _flat2d(g)
+        dh1 = ops.gemm_nt(g2, weight_t(w2))              # [M, r]
+        dpre = ops.relu_bwd(dh1, _flat2d(h1))            # through the ReLU
+        do = dw1 = db1 = dw2 = db2 = None
+        if ctx.needs_input_grad[0]:
+            do = ops.gemm_nt(dpre, weight_t(w1), residual=g2).view(o.shape)  # + identity branch
+        if ctx.needs_input_grad[1]:
+            dw1 = _wgrad(dpre, _flat2d(o))
+        if ctx.needs_input_grad[2]:
+            db1 = ops.colsum(dpre)
+        if ctx.needs_input_grad[3]:
+            dw2 = _wgrad(g2, _flat2d(h1))
+        if ctx.needs_input_grad[4]:
+            db2 = ops.colsum(g2)
+        return do, dw1, db1, dw2, db2
+
+
+def adapter(o, w1, b1, w2, b2):
+    return AdapterFn.apply(o, w1, b1, w2, b2)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """torch.nn.LayerNorm of the layer (megatron/model/norms.py:16-31)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        y, _, mean, rstd = ops.layernorm_fwd(x, w, b, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, grads = ops.layernorm_bwd(dy, x, w, mean, rstd, param_grads=need_p)
+        dw, db = (grads[0], grads[1]) if need_p else (None, None)
+        return dx, dw, db, None
+
+
+def layer_norm(x, w, b, eps):
+    return LayerNormFn.apply(x, w, b, eps)
+
+
+class DualLayerNormFn(torch.autograd.Function):
+    """(LN(x; w1, b1), LN(x; w2, b2)) from one read of x and shared statistics: the GPT-J residual variant
+    normalises the same input twice (megatron/model/transformer.py:737)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, eps):
+        y1, y2, mean, rstd = ops.layernorm_fwd(x, w1, b1, eps, w2, b2)
+        ctx.save_for_backward(x, w1, w2, mean, rstd)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x, w1, w2, mean, rstd = ctx.saved_tensors
+        need_p = any(ctx.needs_input_grad[1:5])
+        dx, grads = ops.layernorm_bwd(dy1, x, w1, mean, rstd, dy2=dy2, w2=w2, param_grads=need_p)
+        if need_p:
+            return dx, grads[0], grads[1], grads[2], grads[3], None
+        return dx, None, None, None, None, None
+
+
+def dual_layer_norm(x, w1, b1, w2, b2, eps):
+    return DualLayerNormFn.apply(x, w1, b1, w2, b2, eps)
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """rotary + scores + mask + softmax + P.V + permute of ParallelSelfAttention
+    (megatron/model/transformer.py:555-630) on the fused QKV activation [s, b, np, 3*hn].
+    The rotary is applied in place on `mixed` (the QKV GEMM's output, not needed again)."""
+
+    @staticmethod
+    def forward(ctx, mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale):
+        s, b = mixed.size(0), mixed.size(1)
+        qkv = mixed.view(s, b, np_, 3 * hn)
+        if rotary_ndims > 0:
+            ops.rotary_qk_inplace(qkv, cos, sin, s, b, np_, hn, rotary_ndims)
+        out, lse = ops.attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask)
+        ctx.save_for_backward(qkv, out, lse, cos, sin, mask)
+        ctx.dims = (s, b, np_, hn, rotary_ndims, softmax_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        qkv, out, lse, cos, sin, mask = ctx.saved_tensors
+        s, b, np_, hn, d, scale = ctx.dims
+        dqkv = ops.attn_bwd(dctx, out, lse, qkv, s, b, np_, hn, scale, mask)
+        if d > 0:
+            ops.rotary_qk_inplace(dqkv, cos, sin, s, b, np_, hn, d, inverse=True)
+        return dqkv.view(s, b, np_ * 3 * hn), None, None, None, None, None, None, None
+
+
+def attention_core(mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale):
+    return AttentionCoreFn.apply(mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale)
+
+
+class BiasDropoutAddFn(torch.autograd.Function):
+    """bias_dropout_add (megatron/model/fused_bias_dropout.py:28-34)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, p, training, seed, offset):
+        drop = training and p > 0
+        if drop:
+            out, keep = ops.bias_dropout_add(x, bias, residual, p, True, seed, offset, want_mask=True)
+            ctx.save_for_backward(keep)
+        else:
+            out = ops.bias_dropout_add(x, bias, residual, 0.0, training)
+        ctx.drop, ctx.p = drop, p
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dx = g
+        if ctx.drop:
+            (keep,) = ctx.saved_tensors
+            dx = (g * keep.to(g.dtype)) * (1.0 / (1.0 - ctx.p))  # rare path (every listed config has p = 0)
+        db = ops.colsum(_flat2d(dx)) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        dres = g if (ctx.has_res and ctx.needs_input_grad[2]) else None
+        return dx, db, dres, None, None, None, None
+
+
+def bias_dropout_add(x, bias, residual, prob, training, seed=0, offset=0):
+    """bias may be a [cols] vector or its expand_as view (the reference passes `bias.expand_as(x)`)."""
+    if bias is not None and bias.dim() > 1:
+        bias = bias.reshape(-1, bias.size(-1))[0] if bias.stride(-1) == 1 and all(st == 0 for st in bias.stride()[:-1]) else bias
+        if bias.dim() > 1:
+            raise RuntimeError("bias_dropout_add: bias must be a vector (or an expanded view of one)")
+    return BiasDropoutAddFn.apply(x, bias, residual, float(prob), bool(training), int(seed), int(offset))
+
+
+class GptjCombineFn(torch.autograd.Function):
+    """out = [x +] ((attn + b_a) + (mlp + b_m)): the GPT-J tail at hidden_dropout = 0 in one kernel."""
+
+    @staticmethod
+    def forward(ctx, x, attn, ba, mlp, bm):
+        ctx.has_x = x is not None
+        return ops.gptj_combine(x, attn, ba, mlp, bm)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        db = ops.colsum(_flat2d(g)) if (ctx.needs_input_grad[2] or ctx.needs_input_grad[4]) else None
+        return (g if ctx.has_x else None), g, (db if ctx.needs_input_grad[2] else None), g, (db if ctx.needs_input_grad[4] else None)
+
+
+def gptj_combine(x, attn, attn_bias, mlp, mlp_bias):
+    return GptjCombineFn.apply(x, attn, attn_bias, mlp, mlp_bias)

@@ -1,0 +1,212 @@
+"""ParallelTransformerLayer and its sub-modules with the reference's constructor / forward signatures,
+sub-module attribute names and parameter names (state-dict compatible with
+megatron/model/transformer.py:71-134, 179-641, 644-813), computing with hand-written gfx950 kernels:
+
+  LayerNorm (one pass, dual output for the GPT-J variant)  ->  QKV GEMM (MFMA, bias epilogue)
+  ->  rotary in place on the fused QKV activation  ->  fused causal / masked attention (no [s, s] tensor)
+  ->  dense GEMM  ->  [adapter: two GEMMs with fused ReLU / residual]  ->  h->4h GEMM with the bias-GeLU epilogue
+  ->  4h->h GEMM  ->  bias-dropout-add / GPT-J combine.
+
+Tensor parallelism follows the reference exactly, including the GPT-J single all-reduce that counts the Row-linear
+biases once per rank (transformer.py:690,703,747-766).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .. import mpu
+from .fused_bias_dropout import (bias_dropout_add_fused_inference, bias_dropout_add_fused_train,
+                                 get_bias_dropout_add)
+from .norms import LayerNorm, get_norm
+from .positional_embeddings import RotaryEmbedding
+from .utils import exists
+
+_CAUSAL_CACHE = {}
+
+
+def _is_plain_causal(mask):
+    """True if `mask` is the lower-triangular [1,1,s,s] mask get_attn_mask builds (megatron/utils.py:66-76) - the only
+    mask the reference's training path ever passes.  Checked once per mask tensor (one device sync), then cached."""
+    if mask is None:
+        return True
+    key = (mask.data_ptr(), tuple(mask.shape), mask._version, str(mask.device))
+    hit = _CAUSAL_CACHE.get(key)
+    if hit is None:
+        ok = mask.dim() == 4 and mask.size(0) == 1 and mask.size(1) == 1 and mask.size(2) == mask.size(3)
+        if ok:
+            s = mask.size(-1)
+            ref = torch.triu(torch.ones(s, s, dtype=torch.bool, device=mask.device), 1)
+            ok = bool(torch.equal(mask.view(s, s).to(torch.bool), ref))
+        if len(_CAUSAL_CACHE) > 64:
+            _CAUSAL_CACHE.clear()
+        _CAUSAL_CACHE[key] = hit = ok
+    return hit
+
+
+class ParallelMLP(nn.Module):
+    """h -> 4h -> h MLP (megatron/model/transformer.py:71-134); returns (output, output_bias)."""
+
+    def __init__(self, neox_args, init_method, output_layer_init_method, parallel_output=False):
+        super().__init__()
+        if neox_args.activation != "gelu":
+            raise NotImplementedError(f"activation {neox_args.activation}: only gelu is on the accelerated path")
+        self.activation_type = neox_args.activation
+        self.bias_gelu_fusion = neox_args.bias_gelu_fusion
+        ff_dim = 4 * neox_args.hidden_size
+        self.dense_h_to_4h = mpu.ColumnParallelLinear(
+            neox_args=neox_args, input_size=neox_args.hidden_size, output_size=ff_dim, gather_output=False,
+            init_method=init_method, skip_bias_add=True)
+        self.dense_4h_to_h = mpu.RowParallelLinear(
+            neox_args=neox_args, input_size=ff_dim, output_size=neox_args.hidden_size, input_is_parallel=True,
+            init_method=output_layer_init_method, skip_bias_add=True, parallel_output=parallel_output)
+
+    def forward(self, hidden_states):
+        # dense_h_to_4h (skip_bias_add) + bias-GeLU in ONE kernel: the activation is the GEMM's epilogue
+        x = mpu.copy_to_model_parallel_region(hidden_states)
+        inter = Fn.linear_bias_gelu(x, self.dense_h_to_4h.weight, self.dense_h_to_4h.bias, 0 if self.bias_gelu_fusion else 1)
+        return self.dense_4h_to_h(inter)
+
+
+class ParallelSelfAttention(nn.Module):
+    """megatron/model/transformer.py:179-641 for pos_emb in {rotary, none}, global attention, no kv-cache."""
+
+    def __init__(self, neox_args, attention_mask_func, init_method, output_layer_init_method, layer_number,
+                 rpe=None, rotary=False, use_cache=False, parallel_output=False):
+        super().__init__()
+        self.fp16 = neox_args.precision == "fp16"
+        self.bf16 = neox_args.precision == "bfloat16"
+        self.attention_mask_func = attention_mask_func
+        self.apply_query_key_layer_scaling = neox_args.apply_query_key_layer_scaling
+        self.use_cache = use_cache
+        self.layer_number = layer_number
+        if rpe is not None or neox_args.pos_emb == "alibi":
+            raise NotImplementedError("rpe / alibi position biases are outside this path's scope")
+        if neox_args.attention_config[layer_number] != "global":
+            raise NotImplementedError("only 'global' attention is on the accelerated path (no flash package, no sparse)")
+        world_size = mpu.get_model_parallel_world_size()
+        self.hidden_size_per_partition = mpu.divide(neox_args.hidden_size, world_size)
+        self.hidden_size_per_attention_head = mpu.divide(neox_args.hidden_size, neox_args.num_attention_heads)
+        self.num_attention_heads_per_partition = mpu.divide(neox_args.num_attention_heads, world_size)
+        self.pos_emb = neox_args.pos_emb
+        self.query_key_value = mpu.ColumnParallelLinear(
+            neox_args=neox_args, input_size=neox_args.hidden_size, output_size=3 * neox_args.hidden_size,
+            gather_output=False, init_method=init_method)
+        self.norm_factor = math.sqrt(self.hidden_size_per_attention_head)
+        if self.apply_query_key_layer_scaling:
+            # scores / (sqrt(hn) * coeff), then softmax(coeff * .) in fp32 (transformer.py:229-233, fused_softmax.py:172):
+            # the two factors cancel in exact arithmetic; the fused kernel computes scores in fp32 anyway.
+            pass
+        if rotary:
+            if neox_args.rotary_pct == 1:
+                self.rotary_ndims = None
+            else:
+                assert neox_args.rotary_pct < 1
+                self.rotary_ndims = int(self.hidden_size_per_attention_head * neox_args.rotary_pct)
+            dim = self.rotary_ndims if self.rotary_ndims is not None else self.hidden_size_per_attention_head
+            self.rotary_emb = RotaryEmbedding(dim, base=neox_args.rotary_emb_base, precision=neox_args.params_dtype)
+        else:
+            self.rotary_emb = None
+        self.upper_triang_fusion = bool(neox_args.scaled_upper_triang_masked_softmax_fusion)
+        self.dropout_p = neox_args.attention_dropout
+        if self.dropout_p != 0:
+            raise NotImplementedError("attention_dropout > 0 is not on the fused path yet (every listed config uses 0)")
+        self.dense = mpu.RowParallelLinear(
+            neox_args=neox_args, input_size=neox_args.hidden_size, output_size=neox_args.hidden_size,
+            input_is_parallel=True, init_method=output_layer_init_method, skip_bias_add=True,
+            parallel_output=parallel_output)
+
+    def forward(self, hidden_states, attention_mask, layer_past=None):
+        if self.use_cache or (exists(layer_past) and layer_past.numel() > 0):
+            raise NotImplementedError("kv-cache inference is outside this path's scope (training hot path only)")
+        s, b = hidden_states.size(0), hidden_states.size(1)
+        np_, hn = self.num_attention_heads_per_partition, self.hidden_size_per_attention_head
+        mixed, _ = self.query_key_value(hidden_states)  # [s, b, np*3*hn], per-head interleaved (q, k, v)
+        cos = sin = None
+        d = 0
+        if exists(self.rotary_emb):
+            d = self.rotary_ndims if exists(self.rotary_ndims) else hn
+            cos, sin = self.rotary_emb.tables(mixed, s)
+        # the fused causal kernel ignores the mask tensor (fused_softmax.py:173-179); otherwise a mask that IS the
+        # plain causal one takes the same fast path (identical result: exp(-10000 - max) == 0 in fp32)
+        mask = None if (self.upper_triang_fusion or _is_plain_causal(attention_mask)) else attention_mask
+        context = Fn.attention_core(mixed, cos, sin, mask, np_, hn, d, 1.0 / self.norm_factor)  # [s, b, np*hn]
+        return self.dense(context)
+
+
+class ParallelTransformerLayer(nn.Module):
+    """A single transformer layer, [s, b, h] -> [s, b, h] (megatron/model/transformer.py:644-801)."""
+
+    def __init__(self, neox_args, attention_mask_func, init_method, output_layer_init_method, layer_number,
+                 rpe=None, rotary=False, use_cache=False):
+        super().__init__()
+        self.layer_number = layer_number
+        norm, eps = get_norm(neox_args)
+        self.input_layernorm = norm(neox_args.hidden_size, eps=eps)
+        self.use_cache = use_cache
+        self.hidden_dropout = neox_args.hidden_dropout
+        self.bias_dropout_fusion = neox_args.bias_dropout_fusion
+        self.gpt_j_residual = neox_args.gpt_j_residual
+        self.gpt_j_tied = neox_args.gpt_j_tied
+        if self.gpt_j_residual:
+            self.reduce = mpu.mappings.reduce_from_model_parallel_region
+        self.attention = ParallelSelfAttention(
+            neox_args=neox_args, attention_mask_func=attention_mask_func, init_method=init_method,
+            output_layer_init_method=output_layer_init_method, layer_number=layer_number, rpe=rpe,
+            use_cache=self.use_cache, rotary=rotary, parallel_output=self.gpt_j_residual)
+        self.post_attention_layernorm = norm(neox_args.hidden_size, eps=eps)
+        self.mlp = ParallelMLP(neox_args=neox_args, init_method=init_method,
+                               output_layer_init_method=output_layer_init_method, parallel_output=self.gpt_j_residual)
+        self.layer_past = None
+        # module dtype follows the engine's cast (`layer.to(dtype)`), like the reference's LayerNorm / inv_freq
+        self.to(neox_args.params_dtype)
+
+    def _get_bias_dropout(self):
+        if self.bias_dropout_fusion:
+            return bias_dropout_add_fused_train if self.training else bias_dropout_add_fused_inference
+        return get_bias_dropout_add(self.training)
+
+    def forward(self, x, attention_mask, layer_past=None):
+        layer_past = layer_past if layer_past is not None else self.layer_past
+        bias_dropout_fn = self._get_bias_dropout()
+        if self.gpt_j_residual:
+            residual = x
+            ln1, ln2 = self.input_layernorm, self.post_attention_layernorm
+            if self.gpt_j_tied:
+                x1 = x2 = ln1(x)
+            elif isinstance(ln1, LayerNorm) and isinstance(ln2, LayerNorm) and ln1.eps == ln2.eps:
+                x1, x2 = Fn.dual_layer_norm(x, ln1.weight, ln1.bias, ln2.weight, ln2.bias, ln1.eps)
+            else:
+                x1, x2 = ln1(x), ln2(x)
+            attention_output, attention_bias = self.attention(x1, attention_mask, layer_past=layer_past)
+            mlp_output, mlp_bias = self.mlp(x2)
+            no_drop = self.hidden_dropout == 0 or not self.training
+            if no_drop:
+                # bias_dropout_add x2 (+ the residual add when TP == 1) in one pass
+                if mpu.get_model_parallel_world_size() == 1:
+                    return Fn.gptj_combine(residual, attention_output, attention_bias, mlp_output, mlp_bias)
+                output = Fn.gptj_combine(None, attention_output, attention_bias, mlp_output, mlp_bias)
+            else:
+                attention_output = bias_dropout_fn(attention_output, bias=attention_bias.expand_as(attention_output),
+                                                   residual=None, prob=self.hidden_dropout)
+                output = bias_dropout_fn(mlp_output, bias=mlp_bias.expand_as(mlp_output), residual=attention_output,
+                                         prob=self.hidden_dropout)
+            # ONE all-reduce of (attn_partial + b_attn + mlp_partial + b_mlp): transformer.py:766
+            return Fn.bias_dropout_add(self.reduce(output), None, residual, 0.0, False)
+        residual = x
+        attention_output, attention_bias = self.attention(self.input_layernorm(x), attention_mask, layer_past=layer_past)
+        attention_output = bias_dropout_fn(attention_output, bias=attention_bias.expand_as(residual), residual=residual,
+                                           prob=self.hidden_dropout)
+        mlp_output, mlp_bias = self.mlp(self.post_attention_layernorm(attention_output))
+        return bias_dropout_fn(mlp_output, bias=mlp_bias.expand_as(attention_output), residual=attention_output,
+                               prob=self.hidden_dropout)
+
+
+class ParallelTransformerLayerPipe(ParallelTransformerLayer):
+    """Forwards the attention mask through a pipeline of layers (megatron/model/transformer.py:804-813)."""
+
+    def forward(self, args):
+        assert len(args) == 2, "ParallelTransformerLayerPipe expects 2 arguments - hidden_states and attention_mask"
+        hidden_states, attention_mask = args
+        return super().forward(hidden_states, attention_mask), attention_mask

@@ -217,6 +217,27 @@ def add(a, b, c=None, out=None):
     return out
 
 
+def relu_bwd(g, act):
+    _need_cuda(g, act)
+    g, act = g.contiguous(), act.contiguous()
+    dx = torch.empty_like(g)
+    check(get_lib().mm_relu_bwd(dx.data_ptr(), g.data_ptr(), act.data_ptr(), g.numel(), dtype_code(g.dtype), _stream()), "relu_bwd")
+    return dx
+
+
+def gptj_combine(x, attn, attn_bias, mlp, mlp_bias):
+    """[x +] ((attn + attn_bias) + (mlp + mlp_bias)) with the eager ops' roundings; x may be None."""
+    _need_cuda(x, attn, attn_bias, mlp, mlp_bias)
+    attn, mlp = attn.contiguous(), mlp.contiguous()
+    cols = attn.size(-1)
+    out = torch.empty_like(attn)
+    xx = x.contiguous() if x is not None else None
+    check(get_lib().mm_gptj_combine(out.data_ptr(), _ptr(xx), attn.data_ptr(), attn_bias.contiguous().data_ptr(), mlp.data_ptr(),
+                                    mlp_bias.contiguous().data_ptr(), attn.numel() // cols, cols, dtype_code(attn.dtype), _stream()),
+          "gptj_combine")
+    return out
+
+
 # ---------------------------------------------------------------------------- GEMM
 def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, want_aux=False):
     """C[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue.  a: [..., K] (flattened to 2D), b: [N, K].

@@ -112,7 +112,4 @@ def test_attention_410m_shape_properties(cuda_device):
     dv = dqkv[..., 2 * hn:].float()
     tot = dv.sum(dim=0)  # [b, np, hn]
     assert (tot / s - 1.0).abs().max() <= 2e-2
-    # dq and dk: rows of P sum to one -> dP - delta has zero P-weighted mean -> sum over keys of dS is 0 -> no check on values,
-    # but both must be finite and non-trivial
     assert torch.isfinite(dqkv.float()).all()
-    assert dqkv[..., :hn].float().abs().max() < 1e-2  # dO.V^T constant across keys => dS = 0 => dq = dk = 0 (up to rounding)
