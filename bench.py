@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py - train tokens/s of `magma_pythia_410M` image-prefix training (bf16) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step of the reference's magma_pythia_410M recipe on one synthetic micro-batch per GPU
+(4 x 2048 tokens: 1 image-prefix token + 2047 caption tokens): prefix projection + embedding + 24
+ParallelTransformerLayers with MAGMA adapters (frozen LM) + final LayerNorm + LM head + masked cross entropy,
+backward, data-parallel gradient all-reduce (RCCL), Adam on the trainable parameters.  Every matmul / attention /
+norm / activation / loss kernel is this repo's HIP code (libmm_hip.so); nothing is skipped or cached.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel: the h->4h MFMA GEMM with
+the fused bias-GeLU epilogue, timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle's
+layer, a bounded sample, on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_FLOPS = 2.5e15   # dense bf16 MFMA, MI355X (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_BPS = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="magma_pythia_410M")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def roofline_dominant_gemm(cfg, device, reps=30):
+    """h->4h GEMM with the bias-GeLU epilogue at the config's shape: HIP events on the current (launch) stream."""
+    from multimodal_amd import _lib, ops
+    T = cfg["micro_batch"] * cfg["seq_length"]
+    h = cfg["hidden_size"]
+    x = torch.randn(T, h, device=device).bfloat16()
+    w = (torch.randn(4 * h, h, device=device) * 0.02).bfloat16()
+    bias = torch.randn(4 * h, device=device).bfloat16()
+    epi = _lib.EPI_BIAS_GELU_TANH if cfg["bias_gelu_fusion"] else _lib.EPI_BIAS_GELU_ERF
+    for _ in range(3):
+        ops.gemm_nt(x, w, bias, epi)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        ops.gemm_nt(x, w, bias, epi)
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    avg_ms = sum(ms) / len(ms)
+    flops = 2.0 * T * h * (4 * h)
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_nt_128_k<bf16, bias_gelu> M=%d N=%d K=%d" % (T, 4 * h, h),
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_FLOPS / 1e12, "unit": "TFLOP/s",
+            "frac": round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), "avg_kernel_ms": round(avg_ms, 4),
+            "median_kernel_ms": round(ms[len(ms) // 2], 4), "flops_per_launch": flops, "traffic": None}
+
+
+def cpu_baseline(cfg, budget_s):
+    """The CPU oracle's layer (+ adapters, frozen LM), fp32, full layer shape, forward + backward, on the host cores.
+    Bounded sample: ONE of the num_layers layers, repeated while the budget lasts; tokens/s is scaled to the whole
+    model by layers (the head is left out, which flatters the CPU)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import golden_params
+    from oracle import neox_layer_oracle as O
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))
+    torch.set_num_threads(threads)
+    h, n, s, b = cfg["hidden_size"], cfg["num_attention_heads"], cfg["seq_length"], cfg["micro_batch"]
+    rng = np.random.default_rng(0)
+    p = {k: v for k, v in golden_params.master_params(rng, h).items()}
+    r = h // cfg["adapter_downsample_factor"]
+    if cfg["add_adapters"]:
+        for loc in ("attention", "mlp"):
+            p[f"{loc}.adapter.0.weight"] = golden_params.rng_t(rng, (r, h), 1e-3).requires_grad_(True)
+            p[f"{loc}.adapter.0.bias"] = golden_params.rng_t(rng, (r,), 1e-3).requires_grad_(True)
+            p[f"{loc}.adapter.2.weight"] = golden_params.rng_t(rng, (h, r), 1e-3).requires_grad_(True)
+            p[f"{loc}.adapter.2.bias"] = golden_params.rng_t(rng, (h,), 1e-3).requires_grad_(True)
+    if not cfg["freeze_lm"]:
+        for k in golden_params.PARAM_ORDER:
+            p[k].requires_grad_(True)
+    ocfg = O.LayerConfig(h, n, rotary_pct=cfg["rotary_pct"], gpt_j_residual=cfg["gpt_j_residual"],
+                         bias_gelu_fusion=cfg["bias_gelu_fusion"])
+    x = golden_params.rng_t(rng, (s, b, h)).requires_grad_(True)
+    dy = golden_params.rng_t(rng, (s, b, h))
+    mask = O.causal_mask(s)
+    times = []
+    t_start = time.time()
+    while True:
+        t0 = time.time()
+        y = O.layer_forward(ocfg, [p], x, mask)
+        y.backward(dy)
+        times.append(time.time() - t0)
+        if time.time() - t_start > budget_s or len(times) >= 6:
+            break
+    t_layer = min(times)
+    tok_s = (s * b) / (t_layer * cfg["num_layers"])
+    return {"value": round(tok_s, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": "CPU oracle (oracle/neox_layer_oracle.py, fp32 eager torch) of 1 of %d layers fwd+bwd at the full shape "
+                      "(s=%d, b=%d, h=%d), best of %d runs = %.3f s/layer, scaled by layers; head/embedding/optimizer excluded"
+                      % (cfg["num_layers"], s, b, h, len(times), t_layer)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    from multimodal_amd import harness, mpu
+    if world > 1:
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    mpu.initialize_model_parallel(1)
+    mpu.model_parallel_cuda_manual_seed(1234)
+    cfg = harness.CONFIGS[a.config]
+    torch.manual_seed(1234 + rank)
+
+    model = harness.MagmaStack(cfg, dtype=torch.bfloat16, device=device)
+    model.train()
+    params = model.trainable_parameters()
+    opt = torch.optim.Adam(params, lr=8e-4, betas=(0.9, 0.95), eps=1e-8, fused=True)  # magma_setup.yml:38-45
+    batches = [harness.synthetic_batch(cfg, device, seed=1000 * rank + i) for i in range(4)]
+    dp_group = mpu.get_data_parallel_group()
+
+    def step(i):
+        enc, tokens, labels, lmask = batches[i % len(batches)]
+        opt.zero_grad(set_to_none=True)
+        loss = model(enc, tokens, labels, lmask)
+        loss.backward()
+        mpu.allreduce_gradients(params, group=dp_group)
+        torch.nn.utils.clip_grad_norm_(params, 1.0)  # gradient_clipping: 1.0 (magma_pythia_410M.yml:57)
+        opt.step()
+        return loss
+
+    losses = []
+    for i in range(a.warmup):
+        losses.append(float(step(i)))
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    losses.append(float(loss))
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    tokens_per_step = cfg["micro_batch"] * cfg["seq_length"] * world
+    value = tokens_per_step * a.steps / dt
+    flops_step = harness.model_flops_per_step(cfg)
+    mfma_util = flops_step * a.steps / dt / PEAK_BF16_FLOPS  # per GPU (weak scaling: every rank does flops_step)
+
+    if rank == 0:
+        roof = roofline_dominant_gemm(cfg, device)
+        out = {
+            "metric": "train tokens/sec (node) magma_pythia_410M", "value": round(value, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "%s image-prefix training step (configs[1]): L=%d h=%d heads=%d s=%d micro_batch=%d/GPU, "
+                                   "1 prefix token + text, adapters r=h/%d trainable, LM frozen, bf16, no activation recompute"
+                                   % (a.config, cfg["num_layers"], cfg["hidden_size"], cfg["num_attention_heads"],
+                                      cfg["seq_length"], cfg["micro_batch"], cfg["adapter_downsample_factor"]),
+                       "global_batch": cfg["micro_batch"] * world, "seq_len": cfg["seq_length"], "parallelism": "dp%d" % world},
+            "mfma_util_model": round(mfma_util, 4),
+            "model_tflops_per_gpu": round(flops_step * a.steps / dt / 1e12, 1),
+            "loss_first_last": [round(losses[0], 4) if losses else None, round(losses[-1], 4)],
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

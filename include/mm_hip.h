@@ -146,6 +146,16 @@ int mm_attn_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, con
                 const void* qkv, const uint8_t* mask, int mask_mode, int mask_batches, int s, int b,
                 int np, int hn, float softmax_scale, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ cross entropy (TP = 1)
+ * Replaces vocab_parallel_cross_entropy(output.float(), labels) (megatron/mpu/cross_entropy.py:27-112 as called from
+ * megatron/model/gpt2_model.py:52-70) for one tensor-parallel rank: loss[t] = logsumexp(logits[t, :]) - logits[t, label[t]],
+ * fp32 math on 16-bit logits [T, V]; lse[T] is saved for the backward. */
+int mm_cross_entropy_fwd(float* loss, float* lse, const void* logits, const int64_t* labels, int T, int V,
+                         int dtype, void* stream);
+/* dlogits[t, v] = (softmax(logits[t])[v] - [v == label[t]]) * row_scale[t]; may alias logits. */
+int mm_cross_entropy_bwd(void* dlogits, const void* logits, const int64_t* labels, const float* lse,
+                         const float* row_scale, int T, int V, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ test-only hardware probe
  * One wave reads a [16][64] 16-bit LDS tile with ds_read_b64_tr_b16; out: [64 lanes][4].  No reference counterpart. */
 int mm_debug_probe_tr_read(void* out, const void* in, const int* row0, const int* col0, void* stream);

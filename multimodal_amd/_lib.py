@@ -43,6 +43,8 @@ PROTOTYPES = {
     "mm_gemm_nt": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
     "mm_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mm_attn_bwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
+    "mm_cross_entropy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mm_cross_entropy_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_debug_probe_tr_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
@@ -57,6 +59,9 @@ def get_lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C multimodal_amd/csrc`). multimodal_amd has no fallback path.")
+        # torch bundles its own libamdhip64.so.7; import it FIRST so that libmm_hip.so binds to the very same HIP
+        # runtime (one runtime per process: streams and device pointers are shared with torch)
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch

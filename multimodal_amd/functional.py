@@ -9,22 +9,15 @@ import torch
 
 from . import _lib, ops
 
-_WT_CACHE = {}  # id(weight) -> (data_ptr, version, W^T)
-
-
 def weight_t(w):
-    """Cached contiguous W^T ([in, out]) of a [out, in] weight."""
-    key = id(w)
-    ent = _WT_CACHE.get(key)
+    """Cached contiguous W^T ([in, out]) of a [out, in] weight.  The cache lives ON the weight object (so it dies with
+    it) and is refreshed when the storage or the version counter changes (optimizer step, .to(device))."""
+    ent = getattr(w, "_mm_wt", None)
     if ent is not None and ent[0] == w.data_ptr() and ent[1] == w._version and ent[2].device == w.device:
         return ent[2]
     wt = ops.transpose2d(w.detach())
-    _WT_CACHE[key] = (w.data_ptr(), w._version, wt)
+    w._mm_wt = (w.data_ptr(), w._version, wt)
     return wt
-
-
-def clear_weight_cache():
-    _WT_CACHE.clear()
 
 
 def _flat2d(t):
@@ -264,3 +257,27 @@ class GptjCombineFn(torch.autograd.Function):
 
 def gptj_combine(x, attn, attn_bias, mlp, mlp_bias):
     return GptjCombineFn.apply(x, attn, attn_bias, mlp, mlp_bias)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """Per-token cross entropy on 16-bit logits with fp32 math (megatron/mpu/cross_entropy.py:27-112 at TP = 1)."""
+
+    @staticmethod
+    def forward(ctx, logits2d, labels):
+        loss, lse = ops.cross_entropy_fwd(logits2d, labels)
+        ctx.save_for_backward(logits2d, labels, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits2d, labels, lse = ctx.saved_tensors
+        # the logits are dead after this: write the gradient over them (saves an 800 MB allocation at V = 50304)
+        return ops.cross_entropy_bwd(logits2d, labels, lse, g.contiguous().float(), out=logits2d), None
+
+
+def masked_cross_entropy(logits, labels, loss_mask):
+    """cross_entropy (megatron/model/gpt2_model.py:52-70): masked mean of the per-token losses."""
+    V = logits.size(-1)
+    losses = CrossEntropyFn.apply(logits.reshape(-1, V), labels.reshape(-1).contiguous())
+    lm = loss_mask.reshape(-1).float()
+    return torch.sum(losses * lm) / lm.sum()

@@ -302,3 +302,24 @@ def _mask_args(mask, s, b):
     m = mask.contiguous()
     m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
     return m, 1, m.size(0)
+
+
+# ---------------------------------------------------------------------------- cross entropy
+def cross_entropy_fwd(logits, labels):
+    """logits [T, V] 16-bit, labels [T] int64 -> (loss [T] fp32, lse [T] fp32)."""
+    _need_cuda(logits, labels)
+    T, V = logits.shape
+    loss = torch.empty(T, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(T, dtype=torch.float32, device=logits.device)
+    check(get_lib().mm_cross_entropy_fwd(loss.data_ptr(), lse.data_ptr(), logits.data_ptr(), labels.data_ptr(), T, V,
+                                         dtype_code(logits.dtype), _stream()), "cross_entropy_fwd")
+    return loss, lse
+
+
+def cross_entropy_bwd(logits, labels, lse, row_scale, out=None):
+    _need_cuda(logits, labels, lse, row_scale)
+    T, V = logits.shape
+    out = torch.empty_like(logits) if out is None else out
+    check(get_lib().mm_cross_entropy_bwd(out.data_ptr(), logits.data_ptr(), labels.data_ptr(), lse.data_ptr(),
+                                         row_scale.data_ptr(), T, V, dtype_code(logits.dtype), _stream()), "cross_entropy_bwd")
+    return out

@@ -285,7 +285,7 @@ def gen_stack():
     from megatron.model.transformer import ParallelTransformerLayer
     from megatron.model.gpt2_model_mask import gpt2_attention_mask_func
 
-    s, b, h, n, L, V, steps = 64, 4, 128, 4, 2, 512, 20
+    s, b, h, n, L, V, steps = 64, 4, 128, 2, 2, 512, 20
     for dt in ("f32", "bf16"):
         rng = np.random.default_rng(99)
         args = make_args(h, n, L, s, dt, 0.25, True, True, 1)
