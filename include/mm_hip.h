@@ -117,7 +117,8 @@ int mm_gptj_combine(void* out, const void* x, const void* attn, const void* attn
  * epilogue: MM_EPI_NONE | MM_EPI_BIAS | MM_EPI_BIAS_GELU_TANH | MM_EPI_BIAS_GELU_ERF (aux [M, N], ld = ldc,
  *           receives the rounded pre-bias product that the reference's GeLU backward re-reads; C the activation)
  *           | MM_EPI_BIAS_RELU (adapter, megatron/model/adapter.py:18-24).
- * Requirements: K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned A/B, 8-byte aligned C/aux/bias. */
+ * MFMA path: K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned A/B, 8-byte aligned C/aux/bias/residual;
+ * anything else (tiny or ragged problems) runs a generic fp32-FMA kernel with the same epilogue semantics. */
 enum {
     MM_EPI_NONE = 0,
     MM_EPI_BIAS = 1,

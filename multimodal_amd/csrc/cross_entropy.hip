@@ -10,6 +10,7 @@ namespace mm {
 
 __device__ __forceinline__ void online_merge(float& m, float& l, float m2, float l2) {
     const float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) return;  // both sides empty (threads beyond V/8 chunks): exp(-inf + inf) would be NaN
     l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
     m = mn;
 }

@@ -181,6 +181,46 @@ __global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* _
     }
 }
 
+
+// ---- generic fallback: any M, N, K, any leading dimension / alignment (tiny or ragged problems such as the image-prefix
+// projection's weight gradient, whose contraction length is the 4-row micro-batch).  16x16 output tile, fp32 FMA.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_generic_k(u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ A,
+                                                         const u16* __restrict__ B, const u16* __restrict__ bias,
+                                                         const u16* __restrict__ Rsd, int M, int N, int K, int lda, int ldb,
+                                                         int ldc, int epi) {
+    __shared__ float sa[16][17], sb[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int ka = k0 + tx;
+        const int am = blockIdx.y * 16 + ty, bn_ = blockIdx.x * 16 + ty;
+        sa[ty][tx] = (am < M && ka < K) ? to_f32<T>(A[(size_t)am * lda + ka]) : 0.f;
+        sb[ty][tx] = (bn_ < N && ka < K) ? to_f32<T>(B[(size_t)bn_ * ldb + ka]) : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc += sa[ty][kk] * sb[tx][kk];
+        __syncthreads();
+    }
+    if (m >= M || n >= N) return;
+    const size_t off = (size_t)m * ldc + n;
+    float o = acc;
+    const float bv = (epi != MM_EPI_NONE) ? to_f32<T>(bias[n]) : 0.f;
+    if (epi == MM_EPI_BIAS_GELU_TANH || epi == MM_EPI_BIAS_GELU_ERF) {
+        const u16 u = from_f32<T>(o);
+        aux[off] = u;
+        const float x = to_f32<T>(u) + bv;
+        o = (epi == MM_EPI_BIAS_GELU_TANH) ? gelu_tanh_dev(x) : gelu_erf_dev(rnd<T>(x));
+    } else if (epi == MM_EPI_BIAS) {
+        o += bv;
+    } else if (epi == MM_EPI_BIAS_RELU) {
+        o = fmaxf(rnd<T>(o + bv), 0.f);
+    }
+    if (Rsd) o = rnd<T>(o) + to_f32<T>(Rsd[off]);
+    C[off] = from_f32<T>(o);
+}
+
 template <typename T, int EPI>
 static int launch_gemm(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N,
                        int K, int lda, int ldb, int ldc, hipStream_t st) {
@@ -204,17 +244,24 @@ extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, cons
                           int N, int K, int lda, int ldb, int ldc, int epilogue, int dtype, void* stream) {
     MM_CHECK_ARG(C && A && B, "mm_gemm_nt: null pointer");
     MM_CHECK_ARG(M > 0 && N > 0 && K > 0, "mm_gemm_nt: M=%d N=%d K=%d must be positive", M, N, K);
-    MM_CHECK_ARG(K % 64 == 0, "mm_gemm_nt: K=%d must be a multiple of 64", K);
-    MM_CHECK_ARG(N % 4 == 0, "mm_gemm_nt: N=%d must be a multiple of 4", N);
     MM_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "mm_gemm_nt: leading dimensions too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
-    MM_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "mm_gemm_nt: lda/ldb must be multiples of 8 and ldc of 4");
-    MM_CHECK_ARG(aligned16(A) && aligned16(B), "mm_gemm_nt: A and B must be 16-byte aligned");
-    MM_CHECK_ARG((((uintptr_t)C) & 7) == 0, "mm_gemm_nt: C must be 8-byte aligned");
     MM_CHECK_ARG(epilogue >= MM_EPI_NONE && epilogue <= MM_EPI_BIAS_RELU, "mm_gemm_nt: unknown epilogue %d", epilogue);
-    if (epilogue != MM_EPI_NONE) MM_CHECK_ARG(bias && (((uintptr_t)bias) & 7) == 0, "mm_gemm_nt: epilogue %d needs an 8-byte aligned bias", epilogue);
+    if (epilogue != MM_EPI_NONE) MM_CHECK_ARG(bias != nullptr, "mm_gemm_nt: epilogue %d needs a bias", epilogue);
     if (epilogue == MM_EPI_BIAS_GELU_TANH || epilogue == MM_EPI_BIAS_GELU_ERF)
-        MM_CHECK_ARG(aux && (((uintptr_t)aux) & 7) == 0, "mm_gemm_nt: GeLU epilogues need an 8-byte aligned aux buffer");
-    if (residual) MM_CHECK_ARG((((uintptr_t)residual) & 7) == 0, "mm_gemm_nt: residual must be 8-byte aligned");
+        MM_CHECK_ARG(aux != nullptr, "mm_gemm_nt: GeLU epilogues need an aux buffer");
+    const bool al8 = ((((uintptr_t)C) | ((uintptr_t)aux) | ((uintptr_t)bias) | ((uintptr_t)residual)) & 7) == 0;
+    const bool mfma_ok = (K % 64 == 0) && (N % 4 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) &&
+                         aligned16(A) && aligned16(B) && al8;
+    if (!mfma_ok) {
+        hipStream_t gst = (hipStream_t)stream;
+        return dispatch_dtype(dtype, [&](auto t) -> int {
+            using T = decltype(t);
+            gemm_nt_generic_k<T><<<dim3((N + 15) / 16, (M + 15) / 16), 256, 0, gst>>>(
+                (u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias, (const u16*)residual, M, N, K, lda, ldb, ldc, epilogue);
+            MM_CHECK_LAUNCH();
+            return (int)MM_OK;
+        });
+    }
     hipStream_t st = (hipStream_t)stream;
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);

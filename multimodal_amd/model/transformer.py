@@ -23,26 +23,23 @@ from .norms import LayerNorm, get_norm
 from .positional_embeddings import RotaryEmbedding
 from .utils import exists
 
-_CAUSAL_CACHE = {}
-
-
 def _is_plain_causal(mask):
     """True if `mask` is the lower-triangular [1,1,s,s] mask get_attn_mask builds (megatron/utils.py:66-76) - the only
-    mask the reference's training path ever passes.  Checked once per mask tensor (one device sync), then cached."""
+    mask the reference's training path ever passes.  Checked once per mask tensor (one device sync); the verdict is
+    cached ON the tensor object together with its version counter and storage address."""
     if mask is None:
         return True
-    key = (mask.data_ptr(), tuple(mask.shape), mask._version, str(mask.device))
-    hit = _CAUSAL_CACHE.get(key)
-    if hit is None:
-        ok = mask.dim() == 4 and mask.size(0) == 1 and mask.size(1) == 1 and mask.size(2) == mask.size(3)
-        if ok:
-            s = mask.size(-1)
-            ref = torch.triu(torch.ones(s, s, dtype=torch.bool, device=mask.device), 1)
-            ok = bool(torch.equal(mask.view(s, s).to(torch.bool), ref))
-        if len(_CAUSAL_CACHE) > 64:
-            _CAUSAL_CACHE.clear()
-        _CAUSAL_CACHE[key] = hit = ok
-    return hit
+    tag = (mask.data_ptr(), mask._version)
+    hit = getattr(mask, "_mm_causal", None)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    ok = mask.dim() == 4 and mask.size(0) == 1 and mask.size(1) == 1 and mask.size(2) == mask.size(3)
+    if ok:
+        s = mask.size(-1)
+        ref = torch.triu(torch.ones(s, s, dtype=torch.bool, device=mask.device), 1)
+        ok = bool(torch.equal(mask.view(s, s).to(torch.bool), ref))
+    mask._mm_causal = (tag, ok)
+    return ok
 
 
 class ParallelMLP(nn.Module):

