@@ -1,0 +1,155 @@
+"""CPU (gloo, world_size 2) tests of the tensor-/data-parallel plumbing: group layout, the four autograd mappings
+(megatron/mpu/mappings.py:110-192 semantics) and the bucketed data-parallel gradient all-reduce."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _worker_tp(rank, world, port, fp32_allreduce):
+    _init(rank, world, port)
+    from multimodal_amd import mpu
+    mpu.initialize_model_parallel(2, fp32_allreduce=fp32_allreduce)
+    assert mpu.get_model_parallel_world_size() == 2 and mpu.get_model_parallel_rank() == rank
+    assert mpu.get_data_parallel_world_size() == 1 and mpu.get_data_parallel_rank() == 0
+    assert mpu.get_model_parallel_src_rank() == 0 and mpu.get_data_parallel_src_rank() == rank
+    dt = torch.bfloat16 if fp32_allreduce else torch.float32
+    # copy: identity forward, all-reduce backward
+    x = torch.arange(6, dtype=torch.float32).view(2, 3).to(dt).requires_grad_(True)
+    y = mpu.copy_to_model_parallel_region(x)
+    assert torch.equal(y, x)
+    (y * (rank + 1)).sum().backward()
+    assert torch.equal(x.grad, torch.full_like(x, 3.0))
+    # reduce: all-reduce forward, identity backward
+    x = torch.full((2, 4), float(rank + 1), dtype=dt, requires_grad=True)
+    y = mpu.reduce_from_model_parallel_region(x * 1.0)
+    assert torch.equal(y, torch.full_like(y, 3.0))
+    (y * 5).sum().backward()
+    assert torch.equal(x.grad, torch.full_like(x, 5.0))
+    # scatter / gather: slices of the last dim, inverse of each other, backward of one is the other
+    full = torch.arange(16, dtype=torch.float32).view(2, 8).to(dt).requires_grad_(True)
+    part = mpu.scatter_to_model_parallel_region(full)
+    assert torch.equal(part, full.detach()[:, 4 * rank:4 * rank + 4])
+    back = mpu.gather_from_model_parallel_region(part)
+    assert torch.equal(back, full.detach())
+    back.sum().backward()
+    assert torch.equal(full.grad, torch.ones_like(full))
+    mpu.destroy_model_parallel()
+    assert mpu.is_unitialized()
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _worker_dp(rank, world, port):
+    _init(rank, world, port)
+    from multimodal_amd import mpu
+    mpu.initialize_model_parallel(1)
+    assert mpu.get_data_parallel_world_size() == 2 and mpu.get_data_parallel_rank() == rank
+    assert mpu.get_model_parallel_world_size() == 1
+    ps = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2).bfloat16()),
+          torch.nn.Parameter(torch.zeros(3))]
+    for i, p in enumerate(ps[:3]):
+        p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+    n = mpu.allreduce_gradients(ps, group=mpu.get_data_parallel_group(), bucket_bytes=64)  # tiny buckets: several calls
+    assert n >= 2
+    for i, p in enumerate(ps[:3]):
+        assert torch.equal(p.grad, torch.full_like(p, 1.5 * (i + 1))), (i, p.grad)
+    assert ps[3].grad is None
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("fp32_allreduce", [False, True])
+def test_tensor_parallel_mappings_world2(fp32_allreduce):
+    mp.spawn(_worker_tp, args=(2, _free_port(), fp32_allreduce), nprocs=2, join=True)
+
+
+def test_data_parallel_gradient_allreduce_world2():
+    mp.spawn(_worker_dp, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_group_layout_matches_reference_docstring():
+    """megatron/mpu/initialize.py:60-66: 8 GPUs, model parallel 2 -> TP [0,1],[2,3],.. ; DP [0,2,4,6],[1,3,5,7]."""
+    from multimodal_amd.mpu import group_layout
+    tp, dp = group_layout(8, 2)
+    assert tp == [[0, 1], [2, 3], [4, 5], [6, 7]] and dp == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    tp, dp = group_layout(8, 8)
+    assert tp == [list(range(8))] and dp == [[i] for i in range(8)]
+    tp, dp = group_layout(8, 1)
+    assert dp == [list(range(8))]
+    with pytest.raises(AssertionError):
+        group_layout(8, 3)
+
+
+def test_single_process_world_and_utils():
+    from multimodal_amd import mpu
+    mpu.destroy_model_parallel()
+    mpu.initialize_model_parallel(1)
+    assert mpu.get_model_parallel_world_size() == 1 and mpu.get_model_parallel_rank() == 0
+    x = torch.randn(3, 4)
+    assert torch.equal(mpu.reduce_from_model_parallel_region(x), x)  # bypass when TP == 1 (mappings.py:33-34)
+    assert mpu.divide(12, 4) == 3
+    a, b = mpu.split_tensor_along_last_dim(torch.arange(8).view(2, 4), 2)
+    assert a.tolist() == [[0, 1], [4, 5]] and not a.is_contiguous()
+    mpu.set_model_parallel_world_size(4)
+    mpu.set_model_parallel_rank(3)
+    assert mpu.get_model_parallel_world_size() == 4 and mpu.get_model_parallel_rank() == 3
+    mpu.destroy_model_parallel()
+
+
+def test_rng_tracker_fork_and_replay():
+    from multimodal_amd import mpu
+    mpu.destroy_model_parallel()
+    mpu.initialize_model_parallel(1)
+    mpu.model_parallel_cuda_manual_seed(1234)
+    tr = mpu.get_cuda_rng_tracker()
+    with tr.fork():
+        s1 = tr.draw()
+        s2 = tr.draw()
+    assert s1[0] == 1234 + 2718 and s2 == (s1[0], s1[1] + 1)
+    assert tr.draw()[0] == 1234  # default stream outside the fork
+    saved = tr.get_states()
+    with tr.fork():
+        a = tr.draw()
+    tr.set_states(saved)
+    with tr.fork():
+        assert tr.draw() == a  # recompute replays the same dropout counters
+    mpu.destroy_model_parallel()
+
+
+def test_neox_layer_config_plumbing_without_gpu():
+    """configs[0] (19M + cpu_mock_config, plumbing without a GPU): the layer builds with the reference's parameter
+    names/shapes on CPU, and calling it fails loudly because the HIP path has no CPU fallback."""
+    from multimodal_amd import harness, mpu
+    from multimodal_amd.model import ParallelTransformerLayer, gpt2_attention_mask_func
+    mpu.destroy_model_parallel()
+    mpu.initialize_model_parallel(1)
+    cfg = harness.CONFIGS["19M"]
+    args = harness.neox_args_for(cfg)
+    args.use_cpu_initialization = True
+    layer = ParallelTransformerLayer(neox_args=args, attention_mask_func=gpt2_attention_mask_func,
+                                     init_method=harness.small_init(512), output_layer_init_method=harness.wang_init(6, 512),
+                                     layer_number=0, rotary=True)
+    shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+    assert shapes["attention.query_key_value.weight"] == (1536, 512) and shapes["mlp.dense_4h_to_h.weight"] == (512, 2048)
+    assert shapes["attention.dense.bias"] == (512,) and "attention.rotary_emb.inv_freq" in shapes
+    assert layer.attention.query_key_value.weight.partition_dim == 0 and layer.mlp.dense_4h_to_h.weight.partition_dim == 1
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.zeros(8, 1, 512, dtype=torch.bfloat16), None)
+    mpu.destroy_model_parallel()
