@@ -130,6 +130,15 @@ enum {
 int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual,
                int M, int N, int K, int lda, int ldb, int ldc, int epilogue, int dtype, void* stream);
 
+/* Weight gradient: C[N, Kp] = A[M, N]^T * B[M, Kp] (contraction over the token dimension M) - the dW = dY^T X half of
+ * F.linear's backward (megatron/mpu/layers.py:557,745; adapter nn.Linear, megatron/model/adapter.py:18-24).
+ * A, B, C row-major (lda, ldb, ldc in elements).  Requirements: N % 128 == 0, Kp % 128 == 0, M % (64*splits) == 0.
+ * splits > 1 splits M over workgroups: workspace is fp32 [splits, N, Kp]; the slabs are summed in a fixed order.
+ * mm_gemm_tn_splits() returns the split count the library would pick (0 = shape not supported: transpose + mm_gemm_nt). */
+int mm_gemm_tn_splits(int M, int N, int Kp);
+int mm_gemm_tn(void* C, float* workspace, const void* A, const void* B, int M, int N, int Kp, int lda, int ldb,
+               int ldc, int splits, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ fused attention
  * Replaces ParallelSelfAttention.attention + the permute after it
  * (megatron/model/transformer.py:315-416, 623-630) without materialising [b*np, s, s].

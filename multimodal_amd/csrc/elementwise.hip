@@ -60,10 +60,10 @@ __global__ __launch_bounds__(256) void rotary_qk_k(u16* __restrict__ qkv, const 
 
 // ------------------------------------------------------------------------------------ GeLU
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    return x * 0.5f * (1.0f + tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x)));
+    return x * 0.5f * (1.0f + fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x)));
 }
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
-    const float t = tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x));
+    const float t = fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x));
     return 0.5f * x * ((1.0f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.0f + t);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -177,13 +177,24 @@ __global__ __launch_bounds__(64) void colsum_partial_k(float* __restrict__ parti
     *reinterpret_cast<f32x4*>(p) = f32x4{acc[0], acc[1], acc[2], acc[3]};
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
 }
+// out[col] = sum_blk partial[blk][col]: 64 columns x 4 row-groups per block, LDS combine
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_final_k(u16* __restrict__ out, const float* __restrict__ partial, int nblk, int cols) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= cols) return;
-    float s = 0.f;
-    for (int bI = 0; bI < nblk; ++bI) s += partial[(size_t)bI * cols + col];
-    out[col] = from_f32<T>(s);
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < cols) {
+        int bI = g;
+        for (; bI + 4 < nblk; bI += 8) {
+            s0 += partial[(size_t)bI * cols + col];
+            s1 += partial[(size_t)(bI + 4) * cols + col];
+        }
+        if (bI < nblk) s0 += partial[(size_t)bI * cols + col];
+    }
+    red[g][cx] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && col < cols) out[col] = from_f32<T>(red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
 }
 
 // ------------------------------------------------------------------------------------ transpose (2-byte elements)
@@ -298,8 +309,8 @@ extern "C" int mm_bias_dropout_add(void* out, const void* x, const void* bias, c
 }
 
 extern "C" int mm_colsum_nblk(int rows) {
-    int n = (rows + 63) / 64;
-    return n < 1 ? 1 : (n > 128 ? 128 : n);
+    int n = (rows + 31) / 32;
+    return n < 1 ? 1 : (n > 256 ? 256 : n);
 }
 
 extern "C" int mm_colsum(void* out, float* partial, const void* x, int rows, int cols, int dtype, void* stream) {
@@ -312,7 +323,7 @@ extern "C" int mm_colsum(void* out, float* partial, const void* x, int rows, int
         using T = decltype(t);
         colsum_partial_k<T><<<dim3((cols + 511) / 512, nblk), 64, 0, st>>>(partial, (const u16*)x, rows, cols, nblk);
         MM_CHECK_LAUNCH();
-        colsum_final_k<T><<<(cols + 255) / 256, 256, 0, st>>>((u16*)out, partial, nblk, cols);
+        colsum_final_k<T><<<(cols + 63) / 64, 256, 0, st>>>((u16*)out, partial, nblk, cols);
         MM_CHECK_LAUNCH();
         return (int)MM_OK;
     });

@@ -38,7 +38,7 @@ template <> struct Mfma<F16> {
 };
 
 __device__ __forceinline__ float gelu_tanh_dev(float x) {
-    return x * 0.5f * (1.0f + tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x)));
+    return x * 0.5f * (1.0f + fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x)));
 }
 __device__ __forceinline__ float gelu_erf_dev(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 

@@ -26,7 +26,7 @@ def _flat2d(t):
 
 def _wgrad(dy2d, x2d):
     """dW[N, K] = dY^T[N, M] . X[M, K]  (contraction over the token dimension)."""
-    return ops.gemm_nt(ops.transpose2d(dy2d), ops.transpose2d(x2d))
+    return ops.gemm_tn(dy2d, x2d)
 
 
 class LinearFn(torch.autograd.Function):

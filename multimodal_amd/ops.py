@@ -267,6 +267,26 @@ def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, wa
     return (c, None) if want_aux else c
 
 
+def gemm_tn(a, b):
+    """C[N, Kp] = A[M, N]^T @ B[M, Kp] (weight gradient).  Uses the transposed-read split-K kernel when the shape allows,
+    otherwise two HBM transposes + gemm_nt."""
+    _need_cuda(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    M, N = a.shape
+    Kp = b.size(1)
+    if b.size(0) != M:
+        raise RuntimeError("gemm_tn: row counts differ")
+    lib = get_lib()
+    splits = lib.mm_gemm_tn_splits(M, N, Kp)
+    if splits == 0:
+        return gemm_nt(transpose2d(a), transpose2d(b))
+    c = torch.empty(N, Kp, dtype=a.dtype, device=a.device)
+    ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=a.device) if splits > 1 else None
+    check(lib.mm_gemm_tn(c.data_ptr(), _ptr(ws), a.data_ptr(), b.data_ptr(), M, N, Kp, N, Kp, Kp, splits,
+                         dtype_code(a.dtype), _stream()), "gemm_tn")
+    return c
+
+
 # ---------------------------------------------------------------------------- attention
 def attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask=None):
     """qkv: contiguous [s, b, np, 3*hn] (post-rotary).  mask None => implicit causal; otherwise a

@@ -335,3 +335,35 @@ def test_cross_entropy_fwd_bwd(ops, cuda_device, T, V):
     assert (lse.cpu() - torch.logsumexp(logits.float(), -1)).abs().max() <= 2e-4
     d = ops.cross_entropy_bwd(logits.to(cuda_device), labels.to(cuda_device), lse, scale.to(cuda_device))
     ulp_close(d, x.grad.bfloat16(), torch.bfloat16, ulps=1, atol=1e-7)
+
+
+# ------------------------------------------------------------------ weight-gradient GEMM (TN, split-K)
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,Kp", [(64, 128, 128), (256, 128, 256), (8192, 128, 1024), (8192, 1024, 128), (1024, 384, 128),
+                                    (192, 128, 128), (100, 128, 128), (256, 96, 128)])
+def test_gemm_tn(ops, cuda_device, dt, M, N, Kp):
+    from multimodal_amd._lib import get_lib
+    torch.manual_seed(M + N + Kp)
+    dtype = DT[dt]
+    a = torch.randn(M, N).to(dtype)
+    b = (torch.randn(M, Kp) / M ** 0.5).to(dtype)
+    got = ops.gemm_tn(a.to(cuda_device), b.to(cuda_device))
+    ref = a.double().t() @ b.double()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert ((got.double().cpu() - ref).abs() <= 2 * eps * ref.abs() + 1e-3).all()
+    splits = get_lib().mm_gemm_tn_splits(M, N, Kp)
+    assert (splits == 0) == (N % 128 != 0 or Kp % 128 != 0 or M % 64 != 0)  # ragged shapes take the transpose + NT route
+    if M == 8192:
+        assert splits == 32  # 8 output tiles x 32 token slices = 256 workgroups for 256 CUs
+
+
+def test_gemm_tn_exact_integers_and_reproducible(ops, cuda_device):
+    """Asymmetric small integers: exact in bf16 and fp32, so any fragment permutation error shows; the slab reduction has a
+    fixed order, so two runs are bit-identical."""
+    M, N, Kp = 512, 128, 256
+    a = ((torch.arange(M * N).view(M, N) * 3) % 7 - 3).float()
+    b = ((torch.arange(M * Kp).view(M, Kp) * 5) % 5 - 2).float()
+    g1 = ops.gemm_tn(a.bfloat16().to(cuda_device), b.bfloat16().to(cuda_device))
+    g2 = ops.gemm_tn(a.bfloat16().to(cuda_device), b.bfloat16().to(cuda_device))
+    assert torch.equal(g1, g2)
+    assert torch.equal(g1.float().cpu(), (a.t() @ b).bfloat16().float())
