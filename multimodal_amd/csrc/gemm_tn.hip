@@ -126,7 +126,7 @@ extern "C" int mm_gemm_tn_splits(int M, int N, int Kp) {
     if (M <= 0 || N <= 0 || Kp <= 0 || N % TN_BT || Kp % TN_BT || M % 64) return 0;  // 0: shape not supported by this kernel
     const int tiles = (N / TN_BT) * (Kp / TN_BT);
     int splits = 1;
-    while (tiles * splits * 2 <= 512 && M % (64 * splits * 2) == 0 && M / (splits * 2) >= 128) splits *= 2;
+    while (tiles * splits * 2 <= 256 && M % (64 * splits * 2) == 0 && M / (splits * 2) >= 128) splits *= 2;
     return splits;
 }
 
