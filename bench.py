@@ -42,32 +42,20 @@ def parse():
     return ap.parse_args()
 
 
-def roofline_dominant_gemm(cfg, device, reps=30):
-    """h->4h GEMM with the bias-GeLU epilogue at the config's shape: HIP events on the current (launch) stream."""
-    from multimodal_amd import _lib, ops
+def roofline_from_probe(cfg, probe):
+    """Dominant kernel = the h->4h GEMM with the fused bias-GeLU epilogue (one launch per layer forward).  Its launches
+    inside the TIMED steps were bracketed by HIP events on the launch stream (ops.GEMM_EVENT_PROBE); average them."""
     T = cfg["micro_batch"] * cfg["seq_length"]
     h = cfg["hidden_size"]
-    x = torch.randn(T, h, device=device).bfloat16()
-    w = (torch.randn(4 * h, h, device=device) * 0.02).bfloat16()
-    bias = torch.randn(4 * h, device=device).bfloat16()
-    epi = _lib.EPI_BIAS_GELU_TANH if cfg["bias_gelu_fusion"] else _lib.EPI_BIAS_GELU_ERF
-    for _ in range(3):
-        ops.gemm_nt(x, w, bias, epi)
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in evs:
-        a.record()
-        ops.gemm_nt(x, w, bias, epi)
-        b.record()
-    torch.cuda.synchronize()
-    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    ms = sorted(a.elapsed_time(b) for a, b, M, N, K in probe["events"] if (M, N, K) == (T, 4 * h, h))
     avg_ms = sum(ms) / len(ms)
     flops = 2.0 * T * h * (4 * h)
     achieved = flops / (avg_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "gemm_nt_128_k<bf16, bias_gelu> M=%d N=%d K=%d" % (T, 4 * h, h),
             "achieved": round(achieved, 2), "peak": PEAK_BF16_FLOPS / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), "avg_kernel_ms": round(avg_ms, 4),
-            "median_kernel_ms": round(ms[len(ms) // 2], 4), "flops_per_launch": flops, "traffic": None}
+            "median_kernel_ms": round(ms[len(ms) // 2], 4), "launches_timed": len(ms), "flops_per_launch": flops,
+            "traffic": None}
 
 
 def cpu_baseline(cfg, budget_s):
@@ -151,20 +139,25 @@ def main():
 
     losses = []
     for i in range(a.warmup):
-        losses.append(float(step(i)))
+        losses.append(float(step(i).detach()))
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    from multimodal_amd import _lib, ops
+    probe = {"epilogue": _lib.EPI_BIAS_GELU_TANH if cfg["bias_gelu_fusion"] else _lib.EPI_BIAS_GELU_ERF, "events": []}
+    if rank == 0:
+        ops.GEMM_EVENT_PROBE = probe
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    losses.append(float(loss))
+    ops.GEMM_EVENT_PROBE = None
+    losses.append(float(loss.detach()))
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -176,7 +169,7 @@ def main():
     mfma_util = flops_step * a.steps / dt / PEAK_BF16_FLOPS  # per GPU (weak scaling: every rank does flops_step)
 
     if rank == 0:
-        roof = roofline_dominant_gemm(cfg, device)
+        roof = roofline_from_probe(cfg, probe)
         out = {
             "metric": "train tokens/sec (node) magma_pythia_410M", "value": round(value, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),

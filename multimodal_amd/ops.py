@@ -239,6 +239,9 @@ def gptj_combine(x, attn, attn_bias, mlp, mlp_bias):
 
 
 # ---------------------------------------------------------------------------- GEMM
+GEMM_EVENT_PROBE = None  # set by bench.py to {"epilogue": code, "events": []} to time one kernel instantiation in situ
+
+
 def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, want_aux=False):
     """C[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue.  a: [..., K] (flattened to 2D), b: [N, K].
     Returns C (and the pre-bias product ``aux`` for the GeLU epilogues)."""
@@ -259,8 +262,15 @@ def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, wa
         aux = torch.empty(M, N, dtype=a.dtype, device=a.device)
     if residual is not None:
         residual = residual.contiguous()
+    probe = GEMM_EVENT_PROBE if (GEMM_EVENT_PROBE is not None and GEMM_EVENT_PROBE["epilogue"] == epilogue) else None
+    if probe is not None:  # bench.py: HIP events around this kernel, on the stream it is launched on
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(get_lib().mm_gemm_nt(c.data_ptr(), _ptr(aux), a2.data_ptr(), b.data_ptr(), _ptr(bias), _ptr(residual), M, N, K,
                                K, K, N, epilogue, dtype_code(a.dtype), _stream()), "gemm_nt")
+    if probe is not None:
+        e1.record()
+        probe["events"].append((e0, e1, M, N, K))
     c = c.view(*a.shape[:-1], N)
     if aux is not None:
         return c, aux.view(*a.shape[:-1], N)
