@@ -63,6 +63,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(u16* __restrict__ ctx, float* 
     const int blk_last = min(q0 + 127, s - 1);
     const int ntiles = (MODE == 0) ? (blk_last / 64 + 1) : ((s + 63) / 64);
     const int wave_last = min(q0 + wave * 32 + 31, s - 1);
+    const int wave_first = q0 + wave * 32;
+    const float mask_raw = kMaskFill * kLog2e / scale_log2e;  // raw score whose scaled value is -10000
     const uint8_t* mrow = nullptr;
     if (MODE == 1) mrow = mask + ((size_t)(mask_batches == 1 ? 0 : bi) * s + qrow_c) * s;
 
@@ -98,40 +100,50 @@ __global__ __launch_bounds__(256) void attn_fwd_k(u16* __restrict__ ctx, float* 
 #pragma unroll
                 for (int ds = 0; ds < NDS; ++ds) sacc[t] = M32<T>::run(row_frag<T, HD>(ks, 32 * t, ds, lane), qf[ds], sacc[t]);
             }
-            float rmax = -INFINITY;
+            // raw scores stay unscaled: max commutes with the positive scale, and p = exp2(fma(s, c, -m)) is one FMA + one exp.
+            // The causal compare/select only runs on tiles that touch this wave's diagonal (wave-uniform test).
+            if (MODE == 1) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kv0 + 32 * t + acc_row(i, hh);
+                        if (key >= s) sacc[t][i] = -INFINITY;
+                        else if (mask_at(mrow, key)) sacc[t][i] = mask_raw;
+                    }
+            } else if (kv0 + 63 > wave_first) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (kv0 + 32 * t + acc_row(i, hh) > qrow) sacc[t][i] = -INFINITY;
+            }
+            float rmax = sacc[0][0];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = kv0 + 32 * t + acc_row(i, hh);
-                    float v = sacc[t][i] * scale_log2e;
-                    if (MODE == 0) {
-                        if (key > qrow) v = -INFINITY;
-                    } else {
-                        if (key >= s) v = -INFINITY;
-                        else if (mask_at(mrow, key)) v = kMaskFill * kLog2e;
-                    }
-                    sacc[t][i] = v;
-                    rmax = fmaxf(rmax, v);
-                }
+                for (int i = 0; i < 16; ++i) rmax = fmaxf(rmax, sacc[t][i]);
             rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-            const float m_new = fmaxf(m_run, rmax);
-            const float alpha = fast_exp2(m_run - m_new);
+            const float m_new = fmaxf(m_run, rmax * scale_log2e);
             float lsum = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = fast_exp2(sacc[t][i] - m_new);
+                    const float p = fast_exp2(__builtin_fmaf(sacc[t][i], scale_log2e, -m_new));
                     sacc[t][i] = p;
                     lsum += p;
                 }
-            l_run = l_run * alpha + lsum;
+            if (__any(m_new > m_run)) {  // the running max moved for some row of this wave: rescale (exact skip otherwise)
+                const float alpha = fast_exp2(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+            }
+            l_run += lsum;
             m_run = m_new;
-#pragma unroll
-            for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -226,6 +238,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(u16* __restrict__ dqkv, con
     const int blk_last = min(q0 + 127, s - 1);
     const int ntiles = (MODE == 0) ? (blk_last / 64 + 1) : ((s + 63) / 64);
     const int wave_last = min(q0 + wave * 32 + 31, s - 1);
+    const int wave_first = q0 + wave * 32;
     const uint8_t* mrow = nullptr;
     if (MODE == 1) mrow = mask + ((size_t)(mask_batches == 1 ? 0 : bi) * s + qrow_c) * s;
 
@@ -262,19 +275,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(u16* __restrict__ dqkv, con
                     sacc = M32<T>::run(row_frag<T, HD>(ks, 32 * t, ds, lane), qf[ds], sacc);
                     dpacc = M32<T>::run(row_frag<T, HD>(vs, 32 * t, ds, lane), dof[ds], dpacc);
                 }
+                if (MODE == 1) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = kv0 + 32 * t + acc_row(i, hh);
-                    float p, live = 1.f;
-                    if (MODE == 0) {
-                        p = (key > qrow) ? 0.f : fast_exp2(sacc[i] * scale_log2e - lse2);
-                    } else {
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kv0 + 32 * t + acc_row(i, hh);
                         const bool dead = key >= s;
                         const bool mk = !dead && mask_at(mrow, key);
-                        p = dead ? 0.f : fast_exp2((mk ? kMaskFill * kLog2e : sacc[i] * scale_log2e) - lse2);
-                        live = mk ? 0.f : 1.f;  // a masked score is the constant -10000: no gradient flows into q.k
+                        const float p = dead ? 0.f : fast_exp2((mk ? kMaskFill * kLog2e : sacc[i] * scale_log2e) - lse2);
+                        // a masked score is the constant -10000: no gradient flows into q.k
+                        sacc[i] = mk ? 0.f : p * (dpacc[i] - dlt);
                     }
-                    sacc[i] = p * (dpacc[i] - dlt) * scale * live;  // dS (w.r.t. the raw q.k product)
+                } else {
+                    const bool diag = kv0 + 32 * t + 31 > wave_first;  // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float p = fast_exp2(__builtin_fmaf(sacc[i], scale_log2e, -lse2));
+                        if (diag && (kv0 + 32 * t + acc_row(i, hh) > qrow)) p = 0.f;
+                        sacc[i] = p * (dpacc[i] - dlt);  // dS / scale; the scale is applied once to dQ at the end
+                    }
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -299,8 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(u16* __restrict__ dqkv, con
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d0 = 32 * d + 8 * g4 + 4 * hh;
-                const u16 a0 = from_f32<T>(dq[d][4 * g4]), a1 = from_f32<T>(dq[d][4 * g4 + 1]);
-                const u16 a2 = from_f32<T>(dq[d][4 * g4 + 2]), a3 = from_f32<T>(dq[d][4 * g4 + 3]);
+                const u16 a0 = from_f32<T>(dq[d][4 * g4] * scale), a1 = from_f32<T>(dq[d][4 * g4 + 1] * scale);
+                const u16 a2 = from_f32<T>(dq[d][4 * g4 + 2] * scale), a3 = from_f32<T>(dq[d][4 * g4 + 3] * scale);
                 *reinterpret_cast<u32x2*>(orow + d0) = u32x2{(uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16)};
             }
     }
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(u16* __restrict__ dqkv, con
 
 // =====================================================================================  backward: dK, dV
 template <typename T, int HD, int MODE>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
+__global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       const u16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                       int mask_batches, int s, int b, int np, float scale_log2e, float scale) {
@@ -397,6 +415,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(u16* __restrict__ dqkv, co
                     dpacc = M32<T>::run(row_frag<T, HD>(os, 32 * t, ds, lane), vf[ds], dpacc);  // dP[q][key]
                 }
                 float pv[16];
+                // wave-uniform: only tiles on this wave's diagonal (or the ragged last tile) pay for the compare/select
+                const bool need_mask = (wave_first + 31 > q0t + 32 * t) || (q0t + 32 * t + 32 > s);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int ql = 32 * t + 8 * g4 + 4 * hh;  // local row of register 4*g4
@@ -406,17 +426,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(u16* __restrict__ dqkv, co
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * g4 + e;
                         const int q = q0t + ql + e;
-                        float p, live = 1.f;
+                        float p;
                         if (MODE == 0) {
-                            p = (krow > q || q >= s) ? 0.f : fast_exp2(sacc[i] * scale_log2e - l4[e]);
+                            p = fast_exp2(__builtin_fmaf(sacc[i], scale_log2e, -l4[e]));
+                            if (need_mask && (krow > q || q >= s)) p = 0.f;
+                            sacc[i] = p * (dpacc[i] - d4[e]);  // dS / scale; the scale is applied once to dK at the end
                         } else {
                             const bool dead = (q >= s) || (krow >= s);
                             const bool mk = !dead && mask_at(mbase + (size_t)q * s, krow);
                             p = dead ? 0.f : fast_exp2((mk ? kMaskFill * kLog2e : sacc[i] * scale_log2e) - l4[e]);
-                            live = mk ? 0.f : 1.f;
+                            sacc[i] = mk ? 0.f : p * (dpacc[i] - d4[e]);
                         }
                         pv[i] = p;
-                        sacc[i] = p * (dpacc[i] - d4[e]) * scale * live;  // dS[q][key]
                     }
                 }
 #pragma unroll
@@ -449,8 +470,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(u16* __restrict__ dqkv, co
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d0 = 32 * d + 8 * g4 + 4 * hh;
-                u16 a0 = from_f32<T>(dk[d][4 * g4]), a1 = from_f32<T>(dk[d][4 * g4 + 1]);
-                u16 a2 = from_f32<T>(dk[d][4 * g4 + 2]), a3 = from_f32<T>(dk[d][4 * g4 + 3]);
+                u16 a0 = from_f32<T>(dk[d][4 * g4] * scale), a1 = from_f32<T>(dk[d][4 * g4 + 1] * scale);
+                u16 a2 = from_f32<T>(dk[d][4 * g4 + 2] * scale), a3 = from_f32<T>(dk[d][4 * g4 + 3] * scale);
                 *reinterpret_cast<u32x2*>(krow_o + d0) = u32x2{(uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16)};
                 a0 = from_f32<T>(dv[d][4 * g4]); a1 = from_f32<T>(dv[d][4 * g4 + 1]);
                 a2 = from_f32<T>(dv[d][4 * g4 + 2]); a3 = from_f32<T>(dv[d][4 * g4 + 3]);
