@@ -34,12 +34,23 @@ constexpr float kMaskFill = -10000.0f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Make a register-resident operand "used" here: the compiler must finish its global load before this point instead of
+// sinking the load to the first MFMA inside the tile loop (where its pending vmcnt would serialise every iteration's
+// prefetch behind the MFMAs).
+template <typename V> __device__ __forceinline__ void pin(V& v) {
+    u32x4 t;
+    __builtin_memcpy(&t, &v, 16);
+    asm volatile("" : "+v"(t));
+    __builtin_memcpy(&v, &t, 16);
+}
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+
 // mask byte for (q, key); mask row base already selected
 __device__ __forceinline__ bool mask_at(const uint8_t* __restrict__ mrow, int key) { return mrow[key] == 1; }
 
 // =====================================================================================  forward
 template <typename T, int HD, int MODE>
-__global__ __launch_bounds__(256) void attn_fwd_k(u16* __restrict__ ctx, float* __restrict__ lse, const u16* __restrict__ qkv,
+__global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __restrict__ ctx, float* __restrict__ lse, const u16* __restrict__ qkv,
                                                   const uint8_t* __restrict__ mask, int mask_batches, int s, int b, int np,
                                                   float scale_log2e) {
     typedef Tile<HD> TL;
@@ -47,8 +58,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(u16* __restrict__ ctx, float* 
     constexpr int NDS = HD / 16, NDB = HD / 32;
     __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES];  // [buf][K | V]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int bi = blockIdx.y / np, hi = blockIdx.y % np;
-    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 128;  // heaviest (latest) query blocks first
+    const int bi = blockIdx.x / np, hi = blockIdx.x % np;  // head-fast grid: see launch_fwd
+    const int q0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 128;  // heaviest (latest) query blocks first
     const size_t tok = (size_t)b * np * 3 * HD;                   // elements between sequence positions
     const u16* qbase = qkv + ((size_t)bi * np + hi) * 3 * HD;
     const u16* kbase = qbase + HD;
@@ -81,6 +92,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(u16* __restrict__ ctx, float* 
     tile_store<HD>(smem, kreg, tid);
     tile_store<HD>(smem + TL::BYTES, vreg, tid);
     __syncthreads();
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) pin(qf[ds]);
 
     for (int j = 0; j < ntiles; ++j) {
         const int cur = j & 1;
@@ -125,15 +138,20 @@ __global__ __launch_bounds__(256) void attn_fwd_k(u16* __restrict__ ctx, float* 
                 for (int i = 0; i < 16; ++i) rmax = fmaxf(rmax, sacc[t][i]);
             rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
             const float m_new = fmaxf(m_run, rmax * scale_log2e);
-            float lsum = 0.f;
+            // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU issue
+            const f32x2 sc2 = {scale_log2e, scale_log2e}, mn2 = {m_new, m_new};
+            f32x2 lsum2 = {0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = fast_exp2(__builtin_fmaf(sacc[t][i], scale_log2e, -m_new));
-                    sacc[t][i] = p;
-                    lsum += p;
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 e = f32x2{sacc[t][i], sacc[t][i + 1]} * sc2 - mn2;
+                    const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
+                    sacc[t][i] = p[0];
+                    sacc[t][i + 1] = p[1];
+                    lsum2 += p;
                 }
+            const float lsum = lsum2[0] + lsum2[1];
             if (__any(m_new > m_run)) {  // the running max moved for some row of this wave: rescale (exact skip otherwise)
                 const float alpha = fast_exp2(m_run - m_new);
                 l_run *= alpha;
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_delta_k(float* __restrict__ delta, c
 
 // =====================================================================================  backward: dQ
 template <typename T, int HD, int MODE>
-__global__ __launch_bounds__(256) void attn_bwd_dq_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
+__global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                      const u16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                      int mask_batches, int s, int b, int np, float scale_log2e, float scale) {
@@ -216,8 +234,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(u16* __restrict__ dqkv, con
     constexpr int NDS = HD / 16, NDB = HD / 32;
     __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int bi = blockIdx.y / np, hi = blockIdx.y % np;
-    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 128;
+    const int bi = blockIdx.x / np, hi = blockIdx.x % np;  // head-fast grid: see launch_fwd
+    const int q0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 128;
     const size_t tok = (size_t)b * np * 3 * HD;
     const u16* qbase = qkv + ((size_t)bi * np + hi) * 3 * HD;
     const u16* kbase = qbase + HD;
@@ -232,8 +250,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(u16* __restrict__ dqkv, con
         qf[ds] = *reinterpret_cast<const frag*>(qbase + (size_t)qrow_c * tok + 16 * ds + 8 * hh);
         dof[ds] = *reinterpret_cast<const frag*>(dorow + 16 * ds + 8 * hh);
     }
-    const float lse2 = lse[((size_t)bi * np + hi) * s + qrow_c] * kLog2e;
-    const float dlt = delta[((size_t)bi * np + hi) * s + qrow_c];
+    const float lse2_ld = lse[((size_t)bi * np + hi) * s + qrow_c] * kLog2e;
+    const float dlt_ld = delta[((size_t)bi * np + hi) * s + qrow_c];
 
     const int blk_last = min(q0 + 127, s - 1);
     const int ntiles = (MODE == 0) ? (blk_last / 64 + 1) : ((s + 63) / 64);
@@ -254,6 +272,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(u16* __restrict__ dqkv, con
     tile_store<HD>(smem, kreg, tid);
     tile_store<HD>(smem + TL::BYTES, vreg, tid);
     __syncthreads();
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+        pin(qf[ds]);
+        pin(dof[ds]);
+    }
+    float lse2 = lse2_ld, dlt = dlt_ld;
+    pin(lse2);
+    pin(dlt);
 
     for (int j = 0; j < ntiles; ++j) {
         const int cur = j & 1;
@@ -337,8 +363,8 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
     __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES + 2 * 2 * 64 * 4];
     float* stat = reinterpret_cast<float*>(smem + 4 * TL::BYTES);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int bi = blockIdx.y / np, hi = blockIdx.y % np;
-    const int k0 = blockIdx.x * 128;  // early key blocks see the most queries: they come first
+    const int bi = blockIdx.x / np, hi = blockIdx.x % np;  // head-fast grid: see launch_fwd
+    const int k0 = blockIdx.y * 128;  // early key blocks see the most queries: they come first
     const size_t tok = (size_t)b * np * 3 * HD;
     const size_t ctok = (size_t)b * np * HD;
     const u16* qbase = qkv + ((size_t)bi * np + hi) * 3 * HD;
@@ -374,13 +400,13 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
         if (tid < 64) {
             int q = row0 + tid;
             q = q < s ? q : s - 1;
-            st_l = lse_bh[q] * kLog2e;
+            st_l = lse_bh[q];  // scaled at store time: touching it here would wait for the load
             st_d = dlt_bh[q];
         }
     };
     auto store_stats = [&](int buf) {
         if (tid < 64) {
-            stat[buf * 128 + tid] = st_l;
+            stat[buf * 128 + tid] = st_l * kLog2e;
             stat[buf * 128 + 64 + tid] = st_d;
         }
     };
@@ -391,6 +417,11 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
     tile_store<HD>(smem + TL::BYTES, oreg, tid);
     store_stats(0);
     __syncthreads();
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+        pin(kf[ds]);
+        pin(vf[ds]);
+    }
 
     for (int j = jt0; j < nqt; ++j) {
         const int cur = (j - jt0) & 1;
@@ -483,7 +514,11 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
 template <typename T, int HD>
 static int launch_fwd(void* ctx, float* lse, const void* qkv, const uint8_t* mask, int mode, int mb, int s, int b, int np,
                       float scale, hipStream_t st) {
-    dim3 grid((s + 127) / 128, b * np), block(256);
+    // Grid: x = (batch, head) - fastest - and y = 128-row block, heaviest causal blocks first.  Dispatch is x-major, so
+    // (1) every heavy block of every head starts before any light one (longest-processing-time order: the causal
+    // triangle's 16:1 work spread no longer leaves a tail), and (2) workgroup id % 8 = head % 8 picks the XCD, so all
+    // blocks that stream one head's K/V share one XCD's L2 instead of spreading every head over all eight.
+    dim3 grid(b * np, (s + 127) / 128), block(256);
     const float sl2 = scale * kLog2e;
     if (mode == 0)
         attn_fwd_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)ctx, lse, (const u16*)qkv, nullptr, 1, s, b, np, sl2);
@@ -500,7 +535,7 @@ static int launch_bwd(void* dqkv, float* delta, const void* dctx, const void* ct
     const size_t nthreads = nrows * (HD / 8);
     attn_delta_k<T, HD><<<(unsigned)((nthreads + 255) / 256), 256, 0, st>>>(delta, (const u16*)dctx, (const u16*)ctx, s, b, np);
     MM_CHECK_LAUNCH();
-    dim3 grid((s + 127) / 128, b * np), block(256);
+    dim3 grid(b * np, (s + 127) / 128), block(256);  // head-fast, heavy blocks first (see launch_fwd)
     const float sl2 = scale * kLog2e;
     if (mode == 0) {
         attn_bwd_dkv_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale);
@@ -523,7 +558,7 @@ static int check_common(const char* fn, int mask_mode, const uint8_t* mask, int 
         MM_CHECK_ARG(mask != nullptr, "%s: mask_mode 1 needs a mask", fn);
         MM_CHECK_ARG(mask_batches == 1 || mask_batches == b, "%s: mask batch %d must be 1 or %d", fn, mask_batches, b);
     }
-    MM_CHECK_ARG((long long)b * np <= 65535, "%s: b*np=%lld exceeds the grid limit", fn, (long long)b * np);
+    MM_CHECK_ARG((s + 127) / 128 <= 65535, "%s: s=%d exceeds the grid limit", fn, s);
     return MM_OK;
 }
 
