@@ -51,7 +51,7 @@ def roofline_from_probe(cfg, probe):
     avg_ms = sum(ms) / len(ms)
     flops = 2.0 * T * h * (4 * h)
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_nt_128_k<bf16, bias_gelu> M=%d N=%d K=%d" % (T, 4 * h, h),
+    return {"bound": "mfma", "kernel": "gemm_nt_256_k<bf16, bias_gelu> M=%d N=%d K=%d" % (T, 4 * h, h),
             "achieved": round(achieved, 2), "peak": PEAK_BF16_FLOPS / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), "avg_kernel_ms": round(avg_ms, 4),
             "median_kernel_ms": round(ms[len(ms) // 2], 4), "launches_timed": len(ms), "flops_per_launch": flops,

@@ -14,33 +14,12 @@
 //     output columns of one row -> 8-byte epilogue stores and 8-byte bias loads;
 //   * blockIdx is remapped so that the blocks of one XCD (blockIdx % 8) walk neighbouring tiles
 //     (shared A row-panels / B column-panels stay in that XCD's L2).
-#include "common.h"
+#include "gemm_common.h"
 
 namespace mm {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
-
-typedef __attribute__((address_space(3))) void lds_void;
-
-template <typename T> struct Mfma;
-template <> struct Mfma<BF16> {
-    typedef bf16x8 frag;
-    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Mfma<F16> {
-    typedef f16x8 frag;
-    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-    }
-};
-
-__device__ __forceinline__ float gelu_tanh_dev(float x) {
-    return x * 0.5f * (1.0f + fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x)));
-}
-__device__ __forceinline__ float gelu_erf_dev(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 // stage one 128x64 tile (rows row0.., k-offset k0) of X (ld elements per row, nrows valid rows) into lds_tile
 template <typename T>
@@ -67,20 +46,8 @@ __global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* _
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
-    // ---- XCD-aware tile mapping (bijective for any grid size), then grouped ordering (8 tile-rows per group)
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    constexpr int GROUP_M = 8;
-    const int group_sz = GROUP_M * tiles_n;
-    const int group = bid / group_sz;
-    const int first_m = group * GROUP_M;
-    const int gm = min(tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (bid % group_sz) % gm;
-    const int tn = (bid % group_sz) / gm;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, 8, tm, tn);
     const int bm = tm * BM, bn = tn * BN;
 
     const int wr = wave >> 1, wc = wave & 1;
@@ -133,52 +100,8 @@ __global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* _
         __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
     }
 
-    // ---- epilogue: lane holds C[m][n0..n0+3], m = bm + wr*64 + mi*16 + frow, n0 = bn + wc*64 + ni*16 + fq*4
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n0 = bn + wc * 64 + ni * 16 + fq * 4;
-        if (n0 >= N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (EPI != MM_EPI_NONE) {
-            const u32x2 braw = *reinterpret_cast<const u32x2*>(bias + n0);
-            bv[0] = to_f32<T>((u16)(braw[0] & 0xffffu)); bv[1] = to_f32<T>((u16)(braw[0] >> 16));
-            bv[2] = to_f32<T>((u16)(braw[1] & 0xffffu)); bv[3] = to_f32<T>((u16)(braw[1] >> 16));
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = bm + wr * 64 + mi * 16 + frow;
-            if (m >= M) continue;
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = acc[ni][mi][j];
-            const size_t off = (size_t)m * ldc + n0;
-            if (EPI == MM_EPI_BIAS_GELU_TANH || EPI == MM_EPI_BIAS_GELU_ERF) {
-                u16 u[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) u[j] = from_f32<T>(o[j]);
-                *reinterpret_cast<u32x2*>(aux + off) = u32x2{(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16)};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x = to_f32<T>(u[j]) + bv[j];
-                    o[j] = (EPI == MM_EPI_BIAS_GELU_TANH) ? gelu_tanh_dev(x) : gelu_erf_dev(rnd<T>(x));
-                }
-            } else if (EPI == MM_EPI_BIAS) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] += bv[j];
-            } else if (EPI == MM_EPI_BIAS_RELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = fmaxf(rnd<T>(o[j] + bv[j]), 0.f);
-            }
-            if (RES) {
-                const u32x2 rr = *reinterpret_cast<const u32x2*>(Rsd + off);
-                o[0] = rnd<T>(o[0]) + to_f32<T>((u16)(rr[0] & 0xffffu)); o[1] = rnd<T>(o[1]) + to_f32<T>((u16)(rr[0] >> 16));
-                o[2] = rnd<T>(o[2]) + to_f32<T>((u16)(rr[1] & 0xffffu)); o[3] = rnd<T>(o[3]) + to_f32<T>((u16)(rr[1] >> 16));
-            }
-            *reinterpret_cast<u32x2*>(C + off) =
-                u32x2{(uint32_t)from_f32<T>(o[0]) | ((uint32_t)from_f32<T>(o[1]) << 16),
-                      (uint32_t)from_f32<T>(o[2]) | ((uint32_t)from_f32<T>(o[3]) << 16)};
-        }
-    }
+    // ---- epilogue (coalesced through a wave-private 8 KiB LDS region; the loop's last barrier retired all LDS traffic)
+    epilogue_staged<T, EPI, RES, 4>(acc, smem + wave * 8192, bm + wr * 64, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd, lane);
 }
 
 
@@ -263,6 +186,10 @@ extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, cons
         });
     }
     hipStream_t st = (hipStream_t)stream;
+    {   // large shapes: the pipelined 256-row kernel (gemm256.hip); it declines (returns 1) what it does not take
+        const int rc = gemm256_try(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, dtype, st);
+        if (rc <= 0) return rc;
+    }
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
         switch (epilogue) {

@@ -1,0 +1,173 @@
+// gemm_common.h - pieces shared by the MFMA GEMM kernels (gemm.hip: 128x128 tile; gemm256.hip: 256-row pipelined tile).
+#pragma once
+#include "common.h"
+
+namespace mm {
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename T> struct Mfma;
+template <> struct Mfma<BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float gelu_tanh_dev(float x) {
+    return x * 0.5f * (1.0f + fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x)));
+}
+__device__ __forceinline__ float gelu_erf_dev(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// XCD-aware tile mapping (bijective for any grid size): the workgroups of one XCD (blockIdx % 8) get a contiguous run of
+// tile ids, walked in groups of `group_m` tile-rows so that the run shares A row-panels / B column-panels in that XCD's L2.
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int group_sz = group_m * tiles_n;
+    const int group = bid / group_sz;
+    const int first_m = group * group_m;
+    const int gm = min(tiles_m - first_m, group_m);
+    tm = first_m + (bid % group_sz) % gm;
+    tn = (bid % group_sz) / gm;
+}
+
+// bias values of 4 consecutive columns
+template <typename T> __device__ __forceinline__ void load_bias4(float (&bv)[4], const u16* __restrict__ bias, int n0) {
+    const u32x2 braw = *reinterpret_cast<const u32x2*>(bias + n0);
+    bv[0] = to_f32<T>((u16)(braw[0] & 0xffffu)); bv[1] = to_f32<T>((u16)(braw[0] >> 16));
+    bv[2] = to_f32<T>((u16)(braw[1] & 0xffffu)); bv[3] = to_f32<T>((u16)(braw[1] >> 16));
+}
+
+// Epilogue of 4 consecutive output columns of one row (fp32 accumulators o[0..3], element offset `off` = m*ldc + n0):
+// the rounding order is the reference's eager order (product rounded, + bias rounded, activation, + residual rounded).
+template <typename T, int EPI, bool RES>
+__device__ __forceinline__ void epilogue4(float (&o)[4], const float (&bv)[4], size_t off, u16* __restrict__ C, u16* __restrict__ aux,
+                                          const u16* __restrict__ Rsd) {
+    if (EPI == MM_EPI_BIAS_GELU_TANH || EPI == MM_EPI_BIAS_GELU_ERF) {
+        u16 u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = from_f32<T>(o[j]);
+        *reinterpret_cast<u32x2*>(aux + off) = u32x2{(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = to_f32<T>(u[j]) + bv[j];
+            o[j] = (EPI == MM_EPI_BIAS_GELU_TANH) ? gelu_tanh_dev(x) : gelu_erf_dev(rnd<T>(x));
+        }
+    } else if (EPI == MM_EPI_BIAS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += bv[j];
+    } else if (EPI == MM_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(rnd<T>(o[j] + bv[j]), 0.f);
+    }
+    if (RES) {
+        const u32x2 rr = *reinterpret_cast<const u32x2*>(Rsd + off);
+        o[0] = rnd<T>(o[0]) + to_f32<T>((u16)(rr[0] & 0xffffu)); o[1] = rnd<T>(o[1]) + to_f32<T>((u16)(rr[0] >> 16));
+        o[2] = rnd<T>(o[2]) + to_f32<T>((u16)(rr[1] & 0xffffu)); o[3] = rnd<T>(o[3]) + to_f32<T>((u16)(rr[1] >> 16));
+    }
+    *reinterpret_cast<u32x2*>(C + off) = u32x2{(uint32_t)from_f32<T>(o[0]) | ((uint32_t)from_f32<T>(o[1]) << 16),
+                                               (uint32_t)from_f32<T>(o[2]) | ((uint32_t)from_f32<T>(o[3]) << 16)};
+}
+
+// ---- coalesced epilogue of one wave's (MI*16) x 64 output tile, staged through a wave-private LDS region.
+// The MFMA accumulator layout gives a lane 4 consecutive columns (8 B) of 16 different rows: stored directly, one wave
+// instruction writes 16 separate 32-byte pieces and every 128-byte line of C is touched by 4 instructions - measured, that
+// store pattern costs as much as the whole K loop at K = 1024.  Instead:
+//   phase 1: epilogue math up to the first rounding, 8-byte ds_write into a [rows][128 B] image (16-byte chunk index
+//            XOR (row>>1)&7: conflict-free for these writes and for the reads below);
+//   phase 2: lane = (row l>>3, chunk l&7) reads 16 B back; one wave instruction now covers 8 full 128-byte rows of C.
+//            Residual add, the GeLU activation and the second output (aux) happen here, on 16-byte coalesced accesses.
+// Rounding order is that of epilogue4 (the reference's eager order).  `wl` must not be shared with another wave; all
+// LDS traffic of the K loop must have completed for every wave (barrier) before the call.
+template <typename T, int EPI, bool RES, int MI>
+__device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char* wl, int m_base, int n_base, int M, int N, int ldc,
+                                                u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ bias,
+                                                const u16* __restrict__ Rsd, int lane) {
+    constexpr bool GELU = (EPI == MM_EPI_BIAS_GELU_TANH || EPI == MM_EPI_BIAS_GELU_ERF);
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n0 = n_base + ni * 16 + fq * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((EPI == MM_EPI_BIAS || EPI == MM_EPI_BIAS_RELU) && n0 < N) load_bias4<T>(bv, bias, n0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = mi * 16 + frow;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = acc[ni][mi][j];
+                if (EPI == MM_EPI_BIAS) o[j] += bv[j];
+                if (EPI == MM_EPI_BIAS_RELU) o[j] = fmaxf(rnd<T>(o[j] + bv[j]), 0.f);
+            }
+            const int phys = (ni * 2 + (fq >> 1)) ^ ((row >> 1) & 7);
+            *reinterpret_cast<u32x2*>(wl + row * 128 + phys * 16 + (fq & 1) * 8) =
+                u32x2{(uint32_t)from_f32<T>(o[0]) | ((uint32_t)from_f32<T>(o[1]) << 16),
+                      (uint32_t)from_f32<T>(o[2]) | ((uint32_t)from_f32<T>(o[3]) << 16)};
+        }
+    }
+    const int c = lane & 7, n = n_base + c * 8;
+    const bool full = n + 8 <= N, half = !full && n + 4 <= N;  // N % 4 == 0 is a precondition of the MFMA kernels
+    float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (GELU) {
+        if (full) {
+            unpack8<T>(*reinterpret_cast<const u32x4*>(bias + n), b8);
+        } else if (half) {
+            float b4[4];
+            load_bias4<T>(b4, bias, n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b8[j] = b4[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI * 2; ++i) {
+        const int row = i * 8 + (lane >> 3);
+        const int m = m_base + row;
+        u32x4 v = *reinterpret_cast<const u32x4*>(wl + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        if (m >= M || !(full || half)) continue;
+        const size_t off = (size_t)m * ldc + n;
+        if (GELU) {
+            if (full) *reinterpret_cast<u32x4*>(aux + off) = v;
+            else *reinterpret_cast<u32x2*>(aux + off) = u32x2{v[0], v[1]};
+        }
+        if (GELU || RES) {
+            float f[8], r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            unpack8<T>(v, f);
+            if (RES) {
+                if (full) {
+                    unpack8<T>(*reinterpret_cast<const u32x4*>(Rsd + off), r8);
+                } else {
+                    const u32x2 rr = *reinterpret_cast<const u32x2*>(Rsd + off);
+                    unpack8<T>(u32x4{rr[0], rr[1], 0u, 0u}, r8);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = f[j];
+                if (GELU) {
+                    x += b8[j];
+                    x = (EPI == MM_EPI_BIAS_GELU_TANH) ? gelu_tanh_dev(x) : gelu_erf_dev(rnd<T>(x));
+                }
+                if (RES) x = (GELU ? rnd<T>(x) : x) + r8[j];
+                f[j] = x;
+            }
+            v = pack8<T>(f);
+        }
+        if (full) *reinterpret_cast<u32x4*>(C + off) = v;
+        else *reinterpret_cast<u32x2*>(C + off) = u32x2{v[0], v[1]};
+    }
+}
+
+// gemm256.hip: returns MM_OK when it ran the problem, 1 when the shape is not one it takes (caller falls back), <0 on error.
+int gemm256_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
+                int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st);
+
+}  // namespace mm

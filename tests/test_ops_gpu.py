@@ -303,6 +303,73 @@ def test_gemm_exact_small_integers(ops, cuda_device):
     assert torch.equal(out.float().cpu(), ref.bfloat16().float())
 
 
+@pytest.fixture
+def force_gemm256():
+    """MM_GEMM256 = 1 forces the 256x256 kernel of gemm256.hip for every legal shape, -1 switches it off."""
+    def setv(v):
+        os.environ["MM_GEMM256"] = str(v)
+    yield setv
+    os.environ.pop("MM_GEMM256", None)
+
+
+@pytest.mark.parametrize("variant", [1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 384, 192), (1000, 1156, 320), (2048, 1024, 1024), (300, 260, 64 * 7)])
+@pytest.mark.parametrize("epi", ["none", "bias", "gelu_tanh", "relu"])
+def test_gemm_nt_256_variants(ops, cuda_device, force_gemm256, variant, M, N, K, epi):
+    """The pipelined 256x256 kernel on ragged M / N (N % 8 == 4 included), odd and even K-tile counts, every epilogue + residual;
+    bit-identical to the 128x128 kernel is not required (different summation order), the fp64 reference bound is."""
+    from multimodal_amd import _lib
+    force_gemm256(variant)
+    torch.manual_seed(M + N + K + variant)
+    a = torch.randn(M, K).bfloat16()
+    b = (torch.randn(N, K) / K ** 0.5).bfloat16()
+    bias = torch.randn(N).bfloat16()
+    res = torch.randn(M, N).bfloat16() if epi in ("bias", "relu") else None
+    code = {"none": _lib.EPI_NONE, "bias": _lib.EPI_BIAS, "gelu_tanh": _lib.EPI_BIAS_GELU_TANH, "relu": _lib.EPI_BIAS_RELU}[epi]
+    dev = lambda t_: None if t_ is None else t_.to(cuda_device)
+    out = ops.gemm_nt(dev(a), dev(b), None if epi == "none" else dev(bias), code, residual=dev(res))
+    aux = None
+    if isinstance(out, tuple):
+        out, aux = out
+    ref = _gemm_ref(a, b, bias, epi, res)
+    err = (out.double().cpu() - ref).abs()
+    assert (err <= 2.0 ** -7 * ref.abs() + 2e-2).all(), f"max err {err.max()}"
+    if aux is not None:
+        uref = a.double() @ b.double().t()
+        assert ((aux.double().cpu() - uref).abs() <= 2.0 ** -7 * uref.abs() + 1e-2).all()
+
+
+@pytest.mark.parametrize("variant", [1])
+def test_gemm_nt_256_exact_integers(ops, cuda_device, force_gemm256, variant):
+    """Asymmetric small-integer operands: every product and partial sum is exact, so any misplaced fragment, stale LDS
+    stage shows as a wrong integer."""
+    force_gemm256(variant)
+    M, N, K = 768, 640, 1024
+    a = (torch.arange(M * K).view(M, K) % 7 - 3).float()
+    b = ((torch.arange(N * K).view(N, K) * 5) % 11 - 5).float()
+    out = ops.gemm_nt(a.bfloat16().to(cuda_device), b.bfloat16().to(cuda_device))
+    assert torch.equal(out.float().cpu(), (a @ b.t()).bfloat16().float())
+
+
+@pytest.mark.parametrize("variant,N,K", [(1, 4096, 1024), (1, 1024, 4096), (1, 3072, 1024)])
+def test_gemm_nt_256_race_screen(ops, cuda_device, force_gemm256, variant, N, K):
+    """The kernel is deterministic, so a read of an LDS stage before its DMA landed (or after it was recycled) shows as a
+    run-to-run difference: 30 launches at the benchmark shapes must agree bit for bit, and with the 128x128 kernel to rounding."""
+    M = 8192
+    torch.manual_seed(N + K)
+    a = torch.randn(M, K, device=cuda_device).bfloat16()
+    b = (torch.randn(N, K, device=cuda_device) / K ** 0.5).bfloat16()
+    force_gemm256(-1)
+    base = ops.gemm_nt(a, b).float()
+    force_gemm256(variant)
+    first = ops.gemm_nt(a, b)
+    for _ in range(30):
+        assert torch.equal(ops.gemm_nt(a, b), first)
+    d = (first.float() - base).abs()
+    assert float(d.max()) <= 2.0 ** -6 * float(base.abs().max())
+    assert float((d > 0).float().mean()) < 0.05   # same products, different fp32 summation order: rare 1-ulp flips only
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 8, 48), (1024, 1024, 4), (5, 7, 3), (130, 36, 100)])
 def test_gemm_generic_fallback_ragged_shapes(ops, cuda_device, M, N, K):
     """Shapes the MFMA kernel does not take (K % 64 != 0, N % 4 != 0) run the generic kernel with the same semantics."""
