@@ -116,7 +116,13 @@ int mm_gptj_combine(void* out, const void* x, const void* attn, const void* attn
  * A, B row-major with leading dimensions lda, ldb (elements); C row-major ldc.
  * epilogue: MM_EPI_NONE | MM_EPI_BIAS | MM_EPI_BIAS_GELU_TANH | MM_EPI_BIAS_GELU_ERF (aux [M, N], ld = ldc,
  *           receives the rounded pre-bias product that the reference's GeLU backward re-reads; C the activation)
- *           | MM_EPI_BIAS_RELU (adapter, megatron/model/adapter.py:18-24).
+ *           | MM_EPI_BIAS_RELU (adapter, megatron/model/adapter.py:18-24)
+ *           | backward epilogues, the data-gradient GEMM fused with the activation's backward kernel; the saved forward
+ *             tensor S [M, N] (ld = ldc) is passed in the `residual` slot:
+ *               MM_EPI_RELU_BWD       C = S > 0 ? round(A B^T) : 0            (S = the ReLU output; torch relu backward)
+ *               MM_EPI_GELU_TANH_BWD  C = round(A B^T) * gelu_tanh'(S + bias) (S = pre-bias product; bias_gelu_back,
+ *                                                                              megatron/model/activations.py:75-86)
+ *               MM_EPI_GELU_ERF_BWD   C = round(A B^T) * gelu_erf'(round(S + bias))   (F.gelu backward).
  * MFMA path: K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned A/B, 8-byte aligned C/aux/bias/residual;
  * anything else (tiny or ragged problems) runs a generic fp32-FMA kernel with the same epilogue semantics. */
 enum {
@@ -124,7 +130,10 @@ enum {
     MM_EPI_BIAS = 1,
     MM_EPI_BIAS_GELU_TANH = 2,
     MM_EPI_BIAS_GELU_ERF = 3,
-    MM_EPI_BIAS_RELU = 4
+    MM_EPI_BIAS_RELU = 4,
+    MM_EPI_RELU_BWD = 5,
+    MM_EPI_GELU_TANH_BWD = 6,
+    MM_EPI_GELU_ERF_BWD = 7
 };
 /* residual (optional, [M, N] with leading dimension ldc, may alias C): C = round(epilogue(...)) + residual. */
 int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual,
@@ -133,11 +142,13 @@ int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bia
 /* Weight gradient: C[N, Kp] = A[M, N]^T * B[M, Kp] (contraction over the token dimension M) - the dW = dY^T X half of
  * F.linear's backward (megatron/mpu/layers.py:557,745; adapter nn.Linear, megatron/model/adapter.py:18-24).
  * A, B, C row-major (lda, ldb, ldc in elements).  Requirements: N % 128 == 0, Kp % 128 == 0, M % (64*splits) == 0.
- * splits > 1 splits M over workgroups: workspace is fp32 [splits, N, Kp]; the slabs are summed in a fixed order.
+ * splits > 1 splits M over workgroups: workspace is fp32 [splits, N*Kp + N]; the slabs are summed in a fixed order.
+ * a_colsum (optional, [N]): also receives the column sums of A - the bias gradient db = sum_m dY[m, :] that the same
+ * backward needs - from the tiles already staged for the GEMM (no extra pass over dY).
  * mm_gemm_tn_splits() returns the split count the library would pick (0 = shape not supported: transpose + mm_gemm_nt). */
 int mm_gemm_tn_splits(int M, int N, int Kp);
-int mm_gemm_tn(void* C, float* workspace, const void* A, const void* B, int M, int N, int Kp, int lda, int ldb,
-               int ldc, int splits, int dtype, void* stream);
+int mm_gemm_tn(void* C, void* a_colsum, float* workspace, const void* A, const void* B, int M, int N, int Kp, int lda,
+               int ldb, int ldc, int splits, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ fused attention
  * Replaces ParallelSelfAttention.attention + the permute after it

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmm_hip.so")
 
 MM_BF16, MM_F16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GELU_ERF, EPI_BIAS_RELU = 0, 1, 2, 3, 4
+EPI_RELU_BWD, EPI_GELU_TANH_BWD, EPI_GELU_ERF_BWD = 5, 6, 7   # backward epilogues: saved forward tensor in the residual slot
 
 c_int, c_float, c_void_p, c_size_t, c_u64 = (
     ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64)
@@ -42,7 +43,7 @@ PROTOTYPES = {
     "mm_gptj_combine": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
     "mm_gemm_nt": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
     "mm_gemm_tn_splits": (c_int, [c_int, c_int, c_int]),
-    "mm_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "mm_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "mm_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mm_attn_bwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
     "mm_cross_entropy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

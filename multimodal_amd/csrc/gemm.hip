@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_nt_generic_k(u16* __restrict__ C, u1
     if (m >= M || n >= N) return;
     const size_t off = (size_t)m * ldc + n;
     float o = acc;
-    const float bv = (epi != MM_EPI_NONE) ? to_f32<T>(bias[n]) : 0.f;
+    const float bv = (epi != MM_EPI_NONE && epi != MM_EPI_RELU_BWD) ? to_f32<T>(bias[n]) : 0.f;
     if (epi == MM_EPI_BIAS_GELU_TANH || epi == MM_EPI_BIAS_GELU_ERF) {
         const u16 u = from_f32<T>(o);
         aux[off] = u;
@@ -140,7 +140,15 @@ __global__ __launch_bounds__(256) void gemm_nt_generic_k(u16* __restrict__ C, u1
     } else if (epi == MM_EPI_BIAS_RELU) {
         o = fmaxf(rnd<T>(o + bv), 0.f);
     }
-    if (Rsd) o = rnd<T>(o) + to_f32<T>(Rsd[off]);
+    if (epi == MM_EPI_RELU_BWD) {
+        o = to_f32<T>(Rsd[off]) > 0.f ? rnd<T>(o) : 0.f;
+    } else if (epi == MM_EPI_GELU_TANH_BWD) {
+        o = rnd<T>(o) * gelu_tanh_grad_dev(to_f32<T>(Rsd[off]) + bv);
+    } else if (epi == MM_EPI_GELU_ERF_BWD) {
+        o = rnd<T>(o) * gelu_erf_grad_dev(rnd<T>(to_f32<T>(Rsd[off]) + bv));
+    } else if (Rsd) {
+        o = rnd<T>(o) + to_f32<T>(Rsd[off]);
+    }
     C[off] = from_f32<T>(o);
 }
 
@@ -149,7 +157,10 @@ static int launch_gemm(void* C, void* aux, const void* A, const void* B, const v
                        int K, int lda, int ldb, int ldc, hipStream_t st) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(256);
-    if (residual)
+    if constexpr (epi_is_bwd(EPI)) {  // the residual slot carries the saved forward tensor: always present
+        gemm_nt_128_k<T, EPI, true><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
+                                                            (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n);
+    } else if (residual)
         gemm_nt_128_k<T, EPI, true><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
                                                             (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n);
     else
@@ -168,8 +179,10 @@ extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, cons
     MM_CHECK_ARG(C && A && B, "mm_gemm_nt: null pointer");
     MM_CHECK_ARG(M > 0 && N > 0 && K > 0, "mm_gemm_nt: M=%d N=%d K=%d must be positive", M, N, K);
     MM_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "mm_gemm_nt: leading dimensions too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
-    MM_CHECK_ARG(epilogue >= MM_EPI_NONE && epilogue <= MM_EPI_BIAS_RELU, "mm_gemm_nt: unknown epilogue %d", epilogue);
-    if (epilogue != MM_EPI_NONE) MM_CHECK_ARG(bias != nullptr, "mm_gemm_nt: epilogue %d needs a bias", epilogue);
+    MM_CHECK_ARG(epilogue >= MM_EPI_NONE && epilogue <= MM_EPI_GELU_ERF_BWD, "mm_gemm_nt: unknown epilogue %d", epilogue);
+    if (epilogue != MM_EPI_NONE && epilogue != MM_EPI_RELU_BWD) MM_CHECK_ARG(bias != nullptr, "mm_gemm_nt: epilogue %d needs a bias", epilogue);
+    if (epi_is_bwd(epilogue))
+        MM_CHECK_ARG(residual != nullptr, "mm_gemm_nt: backward epilogue %d needs the saved forward tensor in `residual`", epilogue);
     if (epilogue == MM_EPI_BIAS_GELU_TANH || epilogue == MM_EPI_BIAS_GELU_ERF)
         MM_CHECK_ARG(aux != nullptr, "mm_gemm_nt: GeLU epilogues need an aux buffer");
     const bool al8 = ((((uintptr_t)C) | ((uintptr_t)aux) | ((uintptr_t)bias) | ((uintptr_t)residual)) & 7) == 0;
@@ -197,7 +210,10 @@ extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, cons
             case MM_EPI_BIAS: return launch_gemm<T, MM_EPI_BIAS>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
             case MM_EPI_BIAS_GELU_TANH: return launch_gemm<T, MM_EPI_BIAS_GELU_TANH>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
             case MM_EPI_BIAS_GELU_ERF: return launch_gemm<T, MM_EPI_BIAS_GELU_ERF>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
-            default: return launch_gemm<T, MM_EPI_BIAS_RELU>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+            case MM_EPI_BIAS_RELU: return launch_gemm<T, MM_EPI_BIAS_RELU>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+            case MM_EPI_RELU_BWD: return launch_gemm<T, MM_EPI_RELU_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+            case MM_EPI_GELU_TANH_BWD: return launch_gemm<T, MM_EPI_GELU_TANH_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+            default: return launch_gemm<T, MM_EPI_GELU_ERF_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
         }
     });
 }

@@ -181,10 +181,10 @@ static int launch256(void* C, void* aux, const void* A, const void* B, const voi
     int group_m = (nwg / 8) / tiles_n;  // one XCD's run of tiles spans whole tile-rows when it can
     group_m = group_m < 1 ? 1 : (group_m > 8 ? 8 : group_m);
     dim3 grid(nwg), block(512);
-    if (residual)
+    if (epi_is_bwd(EPI) || residual)
         gemm_nt_256_k<T, EPI, true><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
                                                                      (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, group_m);
-    else
+    else if constexpr (!epi_is_bwd(EPI))
         gemm_nt_256_k<T, EPI, false><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
                                                                       nullptr, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, group_m);
     MM_CHECK_LAUNCH();
@@ -199,7 +199,10 @@ static int launch256_epi(void* C, void* aux, const void* A, const void* B, const
         case MM_EPI_BIAS: return launch256<T, MM_EPI_BIAS>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
         case MM_EPI_BIAS_GELU_TANH: return launch256<T, MM_EPI_BIAS_GELU_TANH>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
         case MM_EPI_BIAS_GELU_ERF: return launch256<T, MM_EPI_BIAS_GELU_ERF>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
-        default: return launch256<T, MM_EPI_BIAS_RELU>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+        case MM_EPI_BIAS_RELU: return launch256<T, MM_EPI_BIAS_RELU>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+        case MM_EPI_RELU_BWD: return launch256<T, MM_EPI_RELU_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+        case MM_EPI_GELU_TANH_BWD: return launch256<T, MM_EPI_GELU_TANH_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+        default: return launch256<T, MM_EPI_GELU_ERF_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
     }
 }
 

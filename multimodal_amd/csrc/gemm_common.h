@@ -24,6 +24,18 @@ __device__ __forceinline__ float gelu_tanh_dev(float x) {
     return x * 0.5f * (1.0f + fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x)));
 }
 __device__ __forceinline__ float gelu_erf_dev(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// derivatives: the formulas of bias_gelu_back (reference megatron/model/activations.py:75-86) / of erf-GeLU
+__device__ __forceinline__ float gelu_tanh_grad_dev(float x) {
+    const float t = fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x));
+    return 0.5f * x * ((1.0f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_erf_grad_dev(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+// which epilogues read `bias` / use the `residual` slot as a second INPUT (not an addend)
+constexpr bool epi_is_gelu_fwd(int e) { return e == MM_EPI_BIAS_GELU_TANH || e == MM_EPI_BIAS_GELU_ERF; }
+constexpr bool epi_is_gelu_bwd(int e) { return e == MM_EPI_GELU_TANH_BWD || e == MM_EPI_GELU_ERF_BWD; }
+constexpr bool epi_is_bwd(int e) { return e == MM_EPI_RELU_BWD || epi_is_gelu_bwd(e); }
 
 // XCD-aware tile mapping (bijective for any grid size): the workgroups of one XCD (blockIdx % 8) get a contiguous run of
 // tile ids, walked in groups of `group_m` tile-rows so that the run shares A row-panels / B column-panels in that XCD's L2.
@@ -46,37 +58,6 @@ template <typename T> __device__ __forceinline__ void load_bias4(float (&bv)[4],
     bv[2] = to_f32<T>((u16)(braw[1] & 0xffffu)); bv[3] = to_f32<T>((u16)(braw[1] >> 16));
 }
 
-// Epilogue of 4 consecutive output columns of one row (fp32 accumulators o[0..3], element offset `off` = m*ldc + n0):
-// the rounding order is the reference's eager order (product rounded, + bias rounded, activation, + residual rounded).
-template <typename T, int EPI, bool RES>
-__device__ __forceinline__ void epilogue4(float (&o)[4], const float (&bv)[4], size_t off, u16* __restrict__ C, u16* __restrict__ aux,
-                                          const u16* __restrict__ Rsd) {
-    if (EPI == MM_EPI_BIAS_GELU_TANH || EPI == MM_EPI_BIAS_GELU_ERF) {
-        u16 u[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) u[j] = from_f32<T>(o[j]);
-        *reinterpret_cast<u32x2*>(aux + off) = u32x2{(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16)};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float x = to_f32<T>(u[j]) + bv[j];
-            o[j] = (EPI == MM_EPI_BIAS_GELU_TANH) ? gelu_tanh_dev(x) : gelu_erf_dev(rnd<T>(x));
-        }
-    } else if (EPI == MM_EPI_BIAS) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += bv[j];
-    } else if (EPI == MM_EPI_BIAS_RELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaxf(rnd<T>(o[j] + bv[j]), 0.f);
-    }
-    if (RES) {
-        const u32x2 rr = *reinterpret_cast<const u32x2*>(Rsd + off);
-        o[0] = rnd<T>(o[0]) + to_f32<T>((u16)(rr[0] & 0xffffu)); o[1] = rnd<T>(o[1]) + to_f32<T>((u16)(rr[0] >> 16));
-        o[2] = rnd<T>(o[2]) + to_f32<T>((u16)(rr[1] & 0xffffu)); o[3] = rnd<T>(o[3]) + to_f32<T>((u16)(rr[1] >> 16));
-    }
-    *reinterpret_cast<u32x2*>(C + off) = u32x2{(uint32_t)from_f32<T>(o[0]) | ((uint32_t)from_f32<T>(o[1]) << 16),
-                                               (uint32_t)from_f32<T>(o[2]) | ((uint32_t)from_f32<T>(o[3]) << 16)};
-}
-
 // ---- coalesced epilogue of one wave's (MI*16) x 64 output tile, staged through a wave-private LDS region.
 // The MFMA accumulator layout gives a lane 4 consecutive columns (8 B) of 16 different rows: stored directly, one wave
 // instruction writes 16 separate 32-byte pieces and every 128-byte line of C is touched by 4 instructions - measured, that
@@ -85,13 +66,16 @@ __device__ __forceinline__ void epilogue4(float (&o)[4], const float (&bv)[4], s
 //            XOR (row>>1)&7: conflict-free for these writes and for the reads below);
 //   phase 2: lane = (row l>>3, chunk l&7) reads 16 B back; one wave instruction now covers 8 full 128-byte rows of C.
 //            Residual add, the GeLU activation and the second output (aux) happen here, on 16-byte coalesced accesses.
-// Rounding order is that of epilogue4 (the reference's eager order).  `wl` must not be shared with another wave; all
+// Backward epilogues (MM_EPI_RELU_BWD / MM_EPI_GELU_*_BWD) take the saved forward tensor in the residual slot and apply the
+// activation's derivative to the rounded product, i.e. they are the data-gradient GEMM + the elementwise backward kernel.
+// Rounding order is the reference's eager order (product rounded, + bias rounded, activation, + residual rounded).  `wl` must not be shared with another wave; all
 // LDS traffic of the K loop must have completed for every wave (barrier) before the call.
 template <typename T, int EPI, bool RES, int MI>
 __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char* wl, int m_base, int n_base, int M, int N, int ldc,
                                                 u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ bias,
                                                 const u16* __restrict__ Rsd, int lane) {
-    constexpr bool GELU = (EPI == MM_EPI_BIAS_GELU_TANH || EPI == MM_EPI_BIAS_GELU_ERF);
+    constexpr bool GELU = epi_is_gelu_fwd(EPI), GBWD = epi_is_gelu_bwd(EPI), RBWD = (EPI == MM_EPI_RELU_BWD);
+    static_assert(!(GBWD || RBWD) || RES, "backward epilogues take their second input in the residual slot");
     const int frow = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -117,7 +101,7 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
     const int c = lane & 7, n = n_base + c * 8;
     const bool full = n + 8 <= N, half = !full && n + 4 <= N;  // N % 4 == 0 is a precondition of the MFMA kernels
     float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (GELU) {
+    if (GELU || GBWD) {
         if (full) {
             unpack8<T>(*reinterpret_cast<const u32x4*>(bias + n), b8);
         } else if (half) {
@@ -156,7 +140,15 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
                     x += b8[j];
                     x = (EPI == MM_EPI_BIAS_GELU_TANH) ? gelu_tanh_dev(x) : gelu_erf_dev(rnd<T>(x));
                 }
-                if (RES) x = (GELU ? rnd<T>(x) : x) + r8[j];
+                if (RBWD) {
+                    x = r8[j] > 0.f ? x : 0.f;  // r8 = the forward ReLU output
+                } else if (GBWD) {
+                    float u = r8[j] + b8[j];    // r8 = the forward pre-bias product
+                    if (EPI == MM_EPI_GELU_ERF_BWD) u = rnd<T>(u);
+                    x *= (EPI == MM_EPI_GELU_TANH_BWD) ? gelu_tanh_grad_dev(u) : gelu_erf_grad_dev(u);
+                } else if (RES) {
+                    x = (GELU ? rnd<T>(x) : x) + r8[j];
+                }
                 f[j] = x;
             }
             v = pack8<T>(f);

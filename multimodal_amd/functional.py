@@ -29,6 +29,16 @@ def _wgrad(dy2d, x2d):
     return ops.gemm_tn(dy2d, x2d)
 
 
+def _wgrad_bias(dy2d, x2d, need_w, need_b):
+    """(dW, db) of y = x W^T + b: one launch pair gives both when both are wanted (db = column sums of dY, taken from
+    the tiles the weight-gradient GEMM stages anyway)."""
+    if need_w and need_b:
+        return ops.gemm_tn(dy2d, x2d, with_colsum=True)
+    if need_w:
+        return ops.gemm_tn(dy2d, x2d), None
+    return None, (ops.colsum(dy2d) if need_b else None)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T (+ bias) (+ residual): F.linear of the reference's Column/Row linears (mpu/layers.py:557,745)."""
 
@@ -47,10 +57,7 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dy2, weight_t(weight)).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            dw = _wgrad(dy2, _flat2d(x))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2)
+        dw, db = _wgrad_bias(dy2, _flat2d(x), ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres
@@ -81,15 +88,44 @@ class LinearBiasGeluFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(d2, weight_t(weight)).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            dw = _wgrad(d2, _flat2d(x))
-        if ctx.needs_input_grad[2]:
-            db = ops.colsum(d2)
+        dw, db = _wgrad_bias(d2, _flat2d(x), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, None
 
 
 def linear_bias_gelu(x, weight, bias, mode):
     return LinearBiasGeluFn.apply(x, weight, bias, mode)
+
+
+class MlpFn(torch.autograd.Function):
+    """out = gelu(x W1^T + b1) W2^T - both GEMMs of ParallelMLP (megatron/model/transformer.py:118-134; the output bias is
+    returned separately by the module, skip_bias_add).  Forward: bias-GeLU is the first GEMM's epilogue.  Backward: the
+    GeLU derivative is the epilogue of the data-gradient GEMM through W2, so neither direction has an elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, mode):
+        act, pre = ops.gemm_nt(x, w1, b1, _lib.EPI_BIAS_GELU_TANH if mode == 0 else _lib.EPI_BIAS_GELU_ERF)
+        out = ops.gemm_nt(act, w2)
+        ctx.save_for_backward(x, w1, b1, w2, pre, act)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, pre, act = ctx.saved_tensors
+        dy2 = _flat2d(dy.contiguous())
+        dpre = ops.gemm_nt(dy2, weight_t(w2), b1, _lib.EPI_GELU_TANH_BWD if ctx.mode == 0 else _lib.EPI_GELU_ERF_BWD,
+                           residual=_flat2d(pre))
+        dx = dw1 = db1 = dw2 = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(dpre, weight_t(w1)).view(x.shape)
+        dw1, db1 = _wgrad_bias(dpre, _flat2d(x), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        if ctx.needs_input_grad[3]:
+            dw2 = _wgrad(dy2, _flat2d(act))
+        return dx, dw1, db1, dw2, None
+
+
+def mlp(x, w1, b1, w2, mode):
+    return MlpFn.apply(x, w1, b1, w2, mode)
 
 
 class AdapterFn(torch.autograd.Function):
@@ -108,19 +144,13 @@ class AdapterFn(torch.autograd.Function):
         o, w1, w2, h1 = ctx.saved_tensors
         g = g.contiguous()
         g2 = _flat2d(g)
-        dh1 = ops.gemm_nt(g2, weight_t(w2))              # [M, r]
-        dpre = ops.relu_bwd(dh1, _flat2d(h1))            # through the ReLU
-        do = dw1 = db1 = dw2 = db2 = None
+        # [M, r] data gradient through W2 and the ReLU in one kernel (the ReLU mask is the GEMM's epilogue)
+        dpre = ops.gemm_nt(g2, weight_t(w2), None, _lib.EPI_RELU_BWD, residual=_flat2d(h1))
+        do = None
         if ctx.needs_input_grad[0]:
             do = ops.gemm_nt(dpre, weight_t(w1), residual=g2).view(o.shape)  # + identity branch
-        if ctx.needs_input_grad[1]:
-            dw1 = _wgrad(dpre, _flat2d(o))
-        if ctx.needs_input_grad[2]:
-            db1 = ops.colsum(dpre)
-        if ctx.needs_input_grad[3]:
-            dw2 = _wgrad(g2, _flat2d(h1))
-        if ctx.needs_input_grad[4]:
-            db2 = ops.colsum(g2)
+        dw1, db1 = _wgrad_bias(dpre, _flat2d(o), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        dw2, db2 = _wgrad_bias(g2, _flat2d(h1), ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         return do, dw1, db1, dw2, db2
 
 

@@ -61,9 +61,14 @@ class ParallelMLP(nn.Module):
 
     def forward(self, hidden_states):
         # dense_h_to_4h (skip_bias_add) + bias-GeLU in ONE kernel: the activation is the GEMM's epilogue
+        # and, in the backward, its derivative is the epilogue of the data-gradient GEMM through dense_4h_to_h.
+        # TP mappings as in Column/RowParallelLinear (mpu/layers.py:549-565,735-757): copy in, all-reduce out.
         x = mpu.copy_to_model_parallel_region(hidden_states)
-        inter = Fn.linear_bias_gelu(x, self.dense_h_to_4h.weight, self.dense_h_to_4h.bias, 0 if self.bias_gelu_fusion else 1)
-        return self.dense_4h_to_h(inter)
+        row = self.dense_4h_to_h
+        out = Fn.mlp(x, self.dense_h_to_4h.weight, self.dense_h_to_4h.bias, row.weight, 0 if self.bias_gelu_fusion else 1)
+        if not row.parallel_output:
+            out = mpu.reduce_from_model_parallel_region(out)
+        return out, row.bias
 
 
 class ParallelSelfAttention(nn.Module):

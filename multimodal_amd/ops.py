@@ -252,8 +252,10 @@ def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, wa
     M, N = a2.size(0), b.size(0)
     if b.size(1) != K:
         raise RuntimeError(f"gemm_nt: inner dimensions differ ({K} vs {b.size(1)})")
-    if bias is None and epilogue != _lib.EPI_NONE:
+    if bias is None and epilogue not in (_lib.EPI_NONE, _lib.EPI_RELU_BWD):
         raise RuntimeError("gemm_nt: this epilogue needs a bias")
+    if epilogue in (_lib.EPI_RELU_BWD, _lib.EPI_GELU_TANH_BWD, _lib.EPI_GELU_ERF_BWD) and residual is None:
+        raise RuntimeError("gemm_nt: backward epilogues take the saved forward tensor as `residual`")
     if bias is not None and epilogue == _lib.EPI_NONE:
         epilogue = _lib.EPI_BIAS
     c = torch.empty(M, N, dtype=a.dtype, device=a.device) if out is None else out
@@ -277,9 +279,10 @@ def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, wa
     return (c, None) if want_aux else c
 
 
-def gemm_tn(a, b):
-    """C[N, Kp] = A[M, N]^T @ B[M, Kp] (weight gradient).  Uses the transposed-read split-K kernel when the shape allows,
-    otherwise two HBM transposes + gemm_nt."""
+def gemm_tn(a, b, with_colsum=False):
+    """C[N, Kp] = A[M, N]^T @ B[M, Kp] (weight gradient); ``with_colsum`` also returns sum_m A[m, :] (the bias gradient of
+    the same backward) computed from the tiles the GEMM stages anyway.  Uses the transposed-read split-K kernel when the
+    shape allows, otherwise two HBM transposes + gemm_nt (+ the column-sum kernels)."""
     _need_cuda(a, b)
     a, b = a.contiguous(), b.contiguous()
     M, N = a.shape
@@ -289,12 +292,14 @@ def gemm_tn(a, b):
     lib = get_lib()
     splits = lib.mm_gemm_tn_splits(M, N, Kp)
     if splits == 0:
-        return gemm_nt(transpose2d(a), transpose2d(b))
+        c = gemm_nt(transpose2d(a), transpose2d(b))
+        return (c, colsum(a)) if with_colsum else c
     c = torch.empty(N, Kp, dtype=a.dtype, device=a.device)
-    ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=a.device) if splits > 1 else None
-    check(lib.mm_gemm_tn(c.data_ptr(), _ptr(ws), a.data_ptr(), b.data_ptr(), M, N, Kp, N, Kp, Kp, splits,
+    cs = torch.empty(N, dtype=a.dtype, device=a.device) if with_colsum else None
+    ws = torch.empty(splits * (N * Kp + N), dtype=torch.float32, device=a.device) if splits > 1 else None
+    check(lib.mm_gemm_tn(c.data_ptr(), _ptr(cs), _ptr(ws), a.data_ptr(), b.data_ptr(), M, N, Kp, N, Kp, Kp, splits,
                          dtype_code(a.dtype), _stream()), "gemm_tn")
-    return c
+    return (c, cs) if with_colsum else c
 
 
 # ---------------------------------------------------------------------------- attention

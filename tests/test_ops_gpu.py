@@ -418,6 +418,11 @@ def test_gemm_tn(ops, cuda_device, dt, M, N, Kp):
     ref = a.double().t() @ b.double()
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     assert ((got.double().cpu() - ref).abs() <= 2 * eps * ref.abs() + 1e-3).all()
+    # fused bias gradient: same product bit for bit, plus the column sums of the first operand
+    got2, cs = ops.gemm_tn(a.to(cuda_device), b.to(cuda_device), with_colsum=True)
+    assert torch.equal(got2, got)
+    cref = a.double().sum(0)
+    assert ((cs.double().cpu() - cref).abs() <= 2 * eps * cref.abs() + 2 * eps * a.double().abs().sum(0) * 0.05 + 1e-3).all()
     splits = get_lib().mm_gemm_tn_splits(M, N, Kp)
     assert (splits == 0) == (N % 128 != 0 or Kp % 128 != 0 or M % 64 != 0)  # ragged shapes take the transpose + NT route
     if M == 8192:
@@ -434,3 +439,50 @@ def test_gemm_tn_exact_integers_and_reproducible(ops, cuda_device):
     g2 = ops.gemm_tn(a.bfloat16().to(cuda_device), b.bfloat16().to(cuda_device))
     assert torch.equal(g1, g2)
     assert torch.equal(g1.float().cpu(), (a.t() @ b).bfloat16().float())
+    g3, cs = ops.gemm_tn(a.bfloat16().to(cuda_device), b.bfloat16().to(cuda_device), with_colsum=True)
+    assert torch.equal(g3, g1)
+    assert torch.equal(cs.float().cpu(), a.sum(0).bfloat16().float())  # integer column sums: exact
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,force", [(256, 128, 1024, 0), (300, 132, 192, 0), (512, 512, 128, 1), (8192, 128, 1024, 0), (40, 20, 12, 0)])
+@pytest.mark.parametrize("epi", ["relu_bwd", "gelu_tanh_bwd", "gelu_erf_bwd"])
+def test_gemm_nt_backward_epilogues(ops, cuda_device, force_gemm256, dt, M, N, K, force, epi):
+    """Data-gradient GEMM fused with the activation backward == the GEMM followed by this library's own elementwise
+    backward kernels (relu_bwd / bias_gelu_bwd), which test_bias_gelu* / the adapter tests pin to the reference: identical
+    rounding points, so the results agree to the last bit except where the two fp32 summation orders round the product
+    differently (never here: same GEMM kernel, same order)."""
+    from multimodal_amd import _lib
+    if force:
+        force_gemm256(force)
+    torch.manual_seed(M + N + K)
+    dtype = DT[dt]
+    g = torch.randn(M, K).to(dtype).to(cuda_device)
+    w = (torch.randn(N, K) / K ** 0.5).to(dtype).to(cuda_device)
+    bias = torch.randn(N).to(dtype).to(cuda_device)
+    saved = torch.randn(M, N).to(dtype).to(cuda_device)
+    plain = ops.gemm_nt(g, w)
+    if epi == "relu_bwd":
+        act = torch.relu(saved)
+        got = ops.gemm_nt(g, w, None, _lib.EPI_RELU_BWD, residual=act)
+        if N % 8 == 0:
+            want = ops.relu_bwd(plain, act)
+        else:
+            want = torch.where(act > 0, plain, torch.zeros_like(plain))
+    else:
+        mode = 0 if epi == "gelu_tanh_bwd" else 1
+        got = ops.gemm_nt(g, w, bias, _lib.EPI_GELU_TANH_BWD if mode == 0 else _lib.EPI_GELU_ERF_BWD, residual=saved)
+        if N % 8 == 0:
+            want = ops.bias_gelu_bwd(plain, saved, bias, mode)
+        else:
+            x = saved.float() + bias.float()
+            if mode == 1:
+                x = x.to(dtype).float()
+            x = x.double().requires_grad_(True)
+            y = O.bias_gelu_tanh(torch.zeros_like(x), x) if mode == 0 else torch.nn.functional.gelu(x)
+            y.backward(plain.double())
+            want = x.grad.to(dtype)
+    if N % 8 == 0:
+        assert torch.equal(got, want)
+    else:
+        ulp_close(got, want.float(), dtype, ulps=2, atol=1e-3)  # generic kernel vs fp64 autograd: fast-tanh cancellation near 0
