@@ -2,7 +2,7 @@
 (``multimodal_amd.ops``); torch.autograd only sequences them.
 
 Memory policy (MI355X, 288 GB HBM3E): the transposed copy W^T that the data-gradient GEMM wants as its
-K-contiguous operand is cached per weight (refreshed when the weight's version counter moves), so a frozen
+K-contiguous operand is cached per FROZEN weight (refreshed when the weight's version counter moves), so a frozen
 language model (reference `freeze_lm`, megatron/training.py:454-459) pays for the transposes once.
 """
 import torch
@@ -10,8 +10,12 @@ import torch
 from . import _lib, ops
 
 def weight_t(w):
-    """Cached contiguous W^T ([in, out]) of a [out, in] weight.  The cache lives ON the weight object (so it dies with
-    it) and is refreshed when the storage or the version counter changes (optimizer step, .to(device))."""
+    """Contiguous W^T ([in, out]) of a [out, in] weight.  Cached ON the weight object (so it dies with it) for FROZEN
+    weights only, and refreshed when the storage or the version counter changes (load_state_dict, .to(device)).
+    Trainable weights are transposed on every call: fused optimizers (torch.optim.Adam(fused=True)) update parameters
+    without bumping the version counter, so a cache keyed on it would go stale after the first step."""
+    if w.requires_grad:
+        return ops.transpose2d(w.detach())
     ent = getattr(w, "_mm_wt", None)
     if ent is not None and ent[0] == w.data_ptr() and ent[1] == w._version and ent[2].device == w.device:
         return ent[2]

@@ -178,3 +178,34 @@ def test_stack_loss_curve_on_gpu(cuda_device, dt):
     ref = t["losses"].tolist()
     assert max(abs(a - b) for a, b in zip(losses, ref)) <= 0.05, (losses, ref)
     assert losses[-1] < 0.2 * losses[0]
+
+
+@pytest.mark.gpu
+def test_adapter_backward_after_fused_optimizer_step(cuda_device):
+    """torch.optim.Adam(fused=True) updates parameters WITHOUT bumping their version counter: a transposed-weight cache
+    keyed on the counter would feed the data-gradient GEMMs the pre-update weights.  After a large step the input gradient
+    must follow the NEW weights."""
+    from multimodal_amd import functional as Fn
+    torch.manual_seed(3)
+    M, h, r = 256, 512, 64
+    mk = lambda *s, sc=1.0: torch.nn.Parameter((torch.randn(*s, device=cuda_device) * sc).bfloat16())
+    w1, b1, w2, b2 = mk(r, h, sc=h ** -0.5), mk(r), mk(h, r, sc=r ** -0.5), mk(h)
+    opt = torch.optim.Adam([w1, b1, w2, b2], lr=0.05, fused=True)
+    g = torch.randn(M, h, device=cuda_device).bfloat16()
+
+    def run():
+        o = torch.randn(M, h, device=cuda_device, generator=torch.Generator(cuda_device).manual_seed(5)).bfloat16().requires_grad_(True)
+        out = Fn.adapter(o, w1, b1, w2, b2)
+        out.backward(g)
+        return o, o.grad
+
+    run()
+    opt.step()          # weights move by ~lr per element
+    opt.zero_grad()
+    o, do = run()
+    o32 = o.detach().float().requires_grad_(True)
+    h1 = torch.relu((o32 @ w1.float().t() + b1.float()).bfloat16().float())
+    ref_out = o32 + h1 @ w2.float().t() + b2.float()
+    ref_out.backward(g.float())
+    err = (do.float() - o32.grad).abs().max()
+    assert float(err) <= 2.0 ** -6 * float(o32.grad.abs().max()), f"stale weights in the adapter backward? max err {float(err)}"
