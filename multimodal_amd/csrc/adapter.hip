@@ -1,0 +1,300 @@
+// adapter.hip - the MAGMA bottleneck adapter as ONE kernel per direction (gfx950).
+//
+// Reference: megatron/model/adapter.py:18-25,109-117   out = o + W2 relu(W1 o + b1) + b2   (o = the wrapped block's
+// pre-bias output [tokens, h], W1 [r, h], W2 [h, r], r = h / downsample_factor).  The adapter is 2.5 % of the layer's
+// flops but, run as two skinny GEMMs per direction (N = r = 128 gives 64 workgroups; 16 dependent K-steps each), it was
+// 10 % of the step: latency-bound, not bandwidth- or MFMA-bound.  Both directions are the same computation,
+//
+//     H = f1(X Wa^T)  [tokens, r]          Y = f2(H Wb^T) + X  [tokens, h]
+//
+//   forward :  X = o,  Wa = W1, f1 = relu(. + b1),          Wb = W2,   f2 = . + b2      (H = the saved ReLU output)
+//   backward:  X = dY, Wa = W2^T, f1 = mask by saved H > 0, Wb = W1^T, f2 = identity    (H = d(pre-activation), Y = dX)
+//
+// so one kernel template serves both.  Structure: a workgroup owns 32 token rows (256 workgroups at 8192 tokens);
+//   * the 32 x h block of X is staged ONCE into LDS (XOR-swizzled 16-byte chunks) - it is the MFMA operand of the first
+//     product AND the residual of the second, and the output block is assembled in place and stored with full-line writes;
+//   * the weights (2 x 256 KiB, L2-resident, shared by every workgroup) stream through a two-buffer LDS ring in 24 steps
+//     (16 K-tiles of Wa, 8 column chunks of Wb), fetched with COALESCED 16-byte loads into registers several steps ahead
+//     (fully unrolled, so the prefetch distance is just register liveness) - fragment-shaped loads straight from global
+//     memory were tried first and are 8x more L1 accesses per instruction (one line per lane): 26 us, L1-issue-bound;
+//   * H goes through an 8 KiB LDS tile between the two products (and to HBM once, coalesced: the backward needs it);
+//   * one barrier per step: the write of step s into buffer s&1 is ordered after the reads of step s-2 by barrier s-1.
+// Rounding points are exactly those of the unfused path (mm_gemm_nt with MM_EPI_BIAS_RELU / MM_EPI_BIAS + residual /
+// MM_EPI_RELU_BWD / residual), and each output element's K-order is the same, so the results are bit-identical to it.
+#include "gemm_common.h"
+
+namespace mm {
+
+constexpr int AD_BM = 32;
+
+template <typename T, int HID, int R, int MODE>  // MODE 0: forward, 1: backward (data gradient)
+__global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __restrict__ Hout, const u16* __restrict__ X,
+                                                    const u16* __restrict__ Wa, const u16* __restrict__ ba,
+                                                    const u16* __restrict__ Wb, const u16* __restrict__ bb,
+                                                    const u16* __restrict__ Hsaved, int rows) {
+    typedef typename Mfma<T>::frag frag;
+    constexpr int XROW = HID * 2, HROW = R * 2;     // bytes per LDS row of the X block / the H tile
+    constexpr int XCPR = HID / 8, HCPR = R / 8;     // 16-byte chunks per row
+    constexpr int HSW = HCPR >= 16 ? 15 : HCPR - 1; // swizzle mask for rows of HCPR chunks
+    constexpr int NI1 = R / 64;                     // first product: wave owns R/4 columns = NI1 MFMA tiles
+    constexpr int S1 = HID / 64;                    // ... in S1 steps of 64 k (one Wa tile [R][64] each)
+    constexpr int CH2 = 64;                         // second product: chunks of CH2 output columns (Wb rows), 16 per wave
+    constexpr int S2 = HID / CH2;
+    constexpr int KS2 = R / 32;
+    constexpr int L1N = R * 8 / 256;                // 16-byte loads per thread per Wa tile
+    constexpr int L2N = CH2 * HCPR / 256;           // ... per Wb chunk
+    constexpr int LMAX = L1N > L2N ? L1N : L2N;
+    constexpr int RING = (R * 128 > CH2 * HROW) ? R * 128 : CH2 * HROW;  // bytes per ring buffer
+    constexpr int D1 = 8;                           // prefetch distance in steps (Wa tiles and Wb chunks alike): ~128 KiB in flight per CU
+    __shared__ __attribute__((aligned(16))) char smem[AD_BM * XROW + AD_BM * HROW + 2 * RING + HID * 2];
+    char* Xs = smem;
+    char* Hs = smem + AD_BM * XROW;
+    char* Ws = Hs + AD_BM * HROW;
+    char* Bs = Ws + 2 * RING;  // bb staged once (forward)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, frow = lane & 15, fq = lane >> 4;
+    const int m0 = blockIdx.x * AD_BM;
+
+    // ---- weight staging: step s < S1 is Wa tile s, step S1 + c is Wb chunk c
+    u32x4 wreg[S1 + S2][LMAX];
+    auto w_issue = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s < S1) {
+#pragma unroll
+            for (int i = 0; i < L1N; ++i) {
+                const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+                wreg[s][i] = *reinterpret_cast<const u32x4*>(Wa + (size_t)row * HID + s * 64 + ch * 8);
+            }
+        } else if constexpr (s < S1 + S2) {
+#pragma unroll
+            for (int i = 0; i < L2N; ++i) {
+                const int c = tid + 256 * i, row = c / HCPR, ch = c % HCPR;
+                wreg[s][i] = *reinterpret_cast<const u32x4*>(Wb + (size_t)((s - S1) * CH2 + row) * R + ch * 8);
+            }
+        }
+    };
+    auto w_store = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        char* buf = Ws + (s & 1) * RING;
+        if constexpr (s < S1) {
+#pragma unroll
+            for (int i = 0; i < L1N; ++i) {
+                const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+                *reinterpret_cast<u32x4*>(buf + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = wreg[s][i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < L2N; ++i) {
+                const int c = tid + 256 * i, row = c / HCPR, ch = c % HCPR;
+                *reinterpret_cast<u32x4*>(buf + row * HROW + ((ch ^ (row & HSW)) << 4)) = wreg[s][i];
+            }
+        }
+    };
+
+    // ---- small operands first: a load that is issued late is waited for with vmcnt(0), i.e. it drains the whole weight
+    // prefetch queue behind which it sits (vmcnt retires in order) - so nothing but weight tiles is loaded after this point.
+    const int nb1 = wave * (R / 4);
+    u32x2 small1[NI1][2];  // forward: b1 of the lane's H columns ([ni][0]); backward: the saved H values ([ni][mi])
+    u32x4 bbreg = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ni = 0; ni < NI1; ++ni) {
+        const int n0 = nb1 + ni * 16 + fq * 4;
+        if (MODE == 0) {
+            small1[ni][0] = small1[ni][1] = *reinterpret_cast<const u32x2*>(ba + n0);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                small1[ni][mi] = *reinterpret_cast<const u32x2*>(Hsaved + (size_t)min(m0 + mi * 16 + frow, rows - 1) * R + n0);
+        }
+    }
+    if (MODE == 0 && tid < XCPR) bbreg = *reinterpret_cast<const u32x4*>(bb + tid * 8);
+
+    // ---- X block: all loads first (with the first weight tiles behind them), then the LDS writes
+    constexpr int XPASS = AD_BM * XCPR / 256;
+    {
+        u32x4 xr[XPASS];
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const int c = tid + 256 * p, row = c / XCPR, ch = c % XCPR;
+            const int gr = min(m0 + row, rows - 1);
+            xr[p] = *reinterpret_cast<const u32x4*>(X + (size_t)gr * HID + ch * 8);
+        }
+        static_for<0, D1>([&](auto sc) { w_issue(sc); });
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const int c = tid + 256 * p, row = c / XCPR, ch = c % XCPR;
+            *reinterpret_cast<u32x4*>(Xs + row * XROW + ((ch ^ (row & 15)) << 4)) = xr[p];
+        }
+        if (MODE == 0 && tid < XCPR) *reinterpret_cast<u32x4*>(Bs + tid * 16) = bbreg;
+    }
+
+    // ---- first product: H[32, R], wave w owns columns [w*R/4, (w+1)*R/4)
+    f32x4 acc1[NI1][2];
+#pragma unroll
+    for (int i = 0; i < NI1; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for<0, S1>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        w_store(sc);
+        static_for<s + D1, s + D1 + 1>([&](auto nx) { w_issue(nx); });  // (a no-op past the last step)
+        __syncthreads();
+        const char* buf = Ws + (s & 1) * RING;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            frag fa[2], fb[NI1];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                fa[mi] = *reinterpret_cast<const frag*>(Xs + (mi * 16 + frow) * XROW + (((s * 8 + kk * 4 + fq) ^ frow) << 4));
+#pragma unroll
+            for (int ni = 0; ni < NI1; ++ni) {
+                const int n = nb1 + ni * 16 + frow;
+                fb[ni] = *reinterpret_cast<const frag*>(buf + n * 128 + (((kk * 4 + fq) ^ ((n >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI1; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc1[ni][mi] = Mfma<T>::run(fb[ni], fa[mi], acc1[ni][mi]);
+        }
+    });
+    // lane holds H[m = mi*16 + frow][n0 .. n0+3], n0 = nb1 + ni*16 + fq*4
+#pragma unroll
+    for (int ni = 0; ni < NI1; ++ni) {
+        const int n0 = nb1 + ni * 16 + fq * 4;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = mi * 16 + frow;
+            float o[4], sv[4];
+            unpack4<T>(small1[ni][mi], sv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = (MODE == 0) ? fmaxf(rnd<T>(acc1[ni][mi][j] + sv[j]), 0.f) : (sv[j] > 0.f ? acc1[ni][mi][j] : 0.f);
+            *reinterpret_cast<u32x2*>(Hs + m * HROW + (((n0 >> 3) ^ (m & HSW)) << 4) + (fq & 1) * 8) =
+                u32x2{(uint32_t)from_f32<T>(o[0]) | ((uint32_t)from_f32<T>(o[1]) << 16),
+                      (uint32_t)from_f32<T>(o[2]) | ((uint32_t)from_f32<T>(o[3]) << 16)};
+        }
+    }
+
+    // ---- second product: Y[32, HID] = H Wb^T (+ bb) + X in S2 chunks of CH2 columns; wave w owns 16 columns of each chunk
+    frag fh[2][KS2];
+    static_for<0, S2>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, s = S1 + c;
+        w_store(std::integral_constant<int, s>{});
+        static_for<s + D1, s + D1 + 1>([&](auto nx) { w_issue(nx); });
+        __syncthreads();  // (c == 0: also publishes the H tile)
+        if constexpr (c == 0) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks)
+                    fh[mi][ks] = *reinterpret_cast<const frag*>(Hs + (mi * 16 + frow) * HROW + (((ks * 4 + fq) ^ (frow & HSW)) << 4));
+            // H to HBM, 16 bytes per lane, full rows
+#pragma unroll
+            for (int p = 0; p < AD_BM * HCPR / 256; ++p) {
+                const int q = tid + 256 * p, row = q / HCPR, ch = q % HCPR;
+                if (m0 + row < rows)
+                    *reinterpret_cast<u32x4*>(Hout + (size_t)(m0 + row) * R + ch * 8) =
+                        *reinterpret_cast<const u32x4*>(Hs + row * HROW + ((ch ^ (row & HSW)) << 4));
+            }
+        }
+        const char* buf = Ws + (s & 1) * RING;
+        constexpr int NI2 = CH2 / 64;
+        f32x4 acc2[NI2][2];
+#pragma unroll
+        for (int i = 0; i < NI2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < NI2; ++ni) {
+                const int n = wave * (CH2 / 4) + ni * 16 + frow;  // row of the chunk
+                const frag fb = *reinterpret_cast<const frag*>(buf + n * HROW + (((ks * 4 + fq) ^ (n & HSW)) << 4));
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc2[ni][mi] = Mfma<T>::run(fb, fh[mi][ks], acc2[ni][mi]);
+            }
+#pragma unroll
+        for (int ni = 0; ni < NI2; ++ni) {
+            const int n0 = c * CH2 + wave * (CH2 / 4) + ni * 16 + fq * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 0) unpack4<T>(*reinterpret_cast<const u32x2*>(Bs + n0 * 2), bv);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = mi * 16 + frow;
+                u32x2* px = reinterpret_cast<u32x2*>(Xs + m * XROW + (((n0 >> 3) ^ (m & 15)) << 4) + (fq & 1) * 8);
+                const u32x2 xv = *px;  // each X element is read and replaced by the one lane that owns it
+                float o[4];
+                o[0] = rnd<T>(acc2[ni][mi][0] + bv[0]) + to_f32<T>((u16)(xv[0] & 0xffffu));
+                o[1] = rnd<T>(acc2[ni][mi][1] + bv[1]) + to_f32<T>((u16)(xv[0] >> 16));
+                o[2] = rnd<T>(acc2[ni][mi][2] + bv[2]) + to_f32<T>((u16)(xv[1] & 0xffffu));
+                o[3] = rnd<T>(acc2[ni][mi][3] + bv[3]) + to_f32<T>((u16)(xv[1] >> 16));
+                *px = u32x2{(uint32_t)from_f32<T>(o[0]) | ((uint32_t)from_f32<T>(o[1]) << 16),
+                            (uint32_t)from_f32<T>(o[2]) | ((uint32_t)from_f32<T>(o[3]) << 16)};
+            }
+        }
+    });
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < XPASS; ++p) {
+        const int c = tid + 256 * p, row = c / XCPR, ch = c % XCPR;
+        if (m0 + row < rows)
+            *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + row) * HID + ch * 8) =
+                *reinterpret_cast<const u32x4*>(Xs + row * XROW + ((ch ^ (row & 15)) << 4));
+    }
+}
+
+template <typename T, int MODE>
+static int launch_bottleneck(void* Y, void* Hout, const void* X, const void* Wa, const void* ba, const void* Wb, const void* bb,
+                             const void* Hsaved, int rows, int h, int r, hipStream_t st) {
+    dim3 grid((rows + AD_BM - 1) / AD_BM), block(256);
+#define MM_AD_CASE(HID, RR)                                                                                             \
+    if (h == HID && r == RR) {                                                                                          \
+        bottleneck_k<T, HID, RR, MODE><<<grid, block, 0, st>>>((u16*)Y, (u16*)Hout, (const u16*)X, (const u16*)Wa,       \
+                                                               (const u16*)ba, (const u16*)Wb, (const u16*)bb,          \
+                                                               (const u16*)Hsaved, rows);                               \
+        MM_CHECK_LAUNCH();                                                                                              \
+        return MM_OK;                                                                                                   \
+    }
+    MM_AD_CASE(1024, 128)
+    MM_AD_CASE(512, 64)
+#undef MM_AD_CASE
+    return MM_EUNSUPPORTED;
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" int mm_adapter_supported(int h, int r) { return (h == 1024 && r == 128) || (h == 512 && r == 64); }
+
+static int check_adapter(const char* fn, int rows, int h, int r) {
+    MM_CHECK_ARG(rows > 0, "%s: rows=%d must be positive", fn, rows);
+    if (!mm_adapter_supported(h, r)) {
+        mm::set_error("%s: (h=%d, r=%d) is not a fused shape (see mm_adapter_supported); use the mm_gemm_nt path", fn, h, r);
+        return MM_EUNSUPPORTED;
+    }
+    return MM_OK;
+}
+
+extern "C" int mm_adapter_fwd(void* out, void* h1, const void* o, const void* w1, const void* b1, const void* w2, const void* b2,
+                              int rows, int h, int r, int dtype, void* stream) {
+    MM_CHECK_ARG(out && h1 && o && w1 && b1 && w2 && b2, "mm_adapter_fwd: null pointer");
+    if (int rc = check_adapter("mm_adapter_fwd", rows, h, r)) return rc;
+    MM_CHECK_ARG(aligned16(out) && aligned16(h1) && aligned16(o) && aligned16(w1) && aligned16(w2) && aligned16(b1) && aligned16(b2),
+                 "mm_adapter_fwd: pointers must be 16-byte aligned");
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        return launch_bottleneck<T, 0>(out, h1, o, w1, b1, w2, b2, nullptr, rows, h, r, (hipStream_t)stream);
+    });
+}
+
+extern "C" int mm_adapter_bwd_dx(void* dx, void* dpre, const void* dy, const void* w2t, const void* w1t, const void* h1, int rows,
+                                 int h, int r, int dtype, void* stream) {
+    MM_CHECK_ARG(dx && dpre && dy && w2t && w1t && h1, "mm_adapter_bwd_dx: null pointer");
+    if (int rc = check_adapter("mm_adapter_bwd_dx", rows, h, r)) return rc;
+    MM_CHECK_ARG(aligned16(dx) && aligned16(dpre) && aligned16(dy) && aligned16(w2t) && aligned16(w1t) && aligned16(h1),
+                 "mm_adapter_bwd_dx: pointers must be 16-byte aligned");
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        return launch_bottleneck<T, 1>(dx, dpre, dy, w2t, nullptr, w1t, nullptr, h1, rows, h, r, (hipStream_t)stream);
+    });
+}

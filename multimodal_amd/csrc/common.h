@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <type_traits>
 #include "../../include/mm_hip.h"
 
 namespace mm {
@@ -28,6 +29,14 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 constexpr int kWave = 64;
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E) - indices usable as template arguments
+template <int B, int E, typename F> __host__ __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 typedef uint16_t u16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;

@@ -51,6 +51,10 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
     tn = (bid % group_sz) / gm;
 }
 
+template <typename T> __device__ __forceinline__ void unpack4(const u32x2& v, float (&f)[4]) {
+    f[0] = to_f32<T>((u16)(v[0] & 0xffffu)); f[1] = to_f32<T>((u16)(v[0] >> 16));
+    f[2] = to_f32<T>((u16)(v[1] & 0xffffu)); f[3] = to_f32<T>((u16)(v[1] >> 16));
+}
 // bias values of 4 consecutive columns
 template <typename T> __device__ __forceinline__ void load_bias4(float (&bv)[4], const u16* __restrict__ bias, int n0) {
     const u32x2 braw = *reinterpret_cast<const u32x2*>(bias + n0);

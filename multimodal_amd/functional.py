@@ -138,8 +138,11 @@ class AdapterFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, o, w1, b1, w2, b2):
-        h1 = ops.gemm_nt(o, w1, b1, _lib.EPI_BIAS_RELU)
-        out = ops.gemm_nt(h1, w2, b2, _lib.EPI_BIAS, residual=o)
+        if ops.adapter_supported(w1.size(1), w1.size(0)):
+            out, h1 = ops.adapter_fwd(o, w1, b1, w2, b2)           # one kernel (csrc/adapter.hip)
+        else:
+            h1 = ops.gemm_nt(o, w1, b1, _lib.EPI_BIAS_RELU)
+            out = ops.gemm_nt(h1, w2, b2, _lib.EPI_BIAS, residual=o)
         ctx.save_for_backward(o, w1, w2, h1)
         return out
 
@@ -148,11 +151,15 @@ class AdapterFn(torch.autograd.Function):
         o, w1, w2, h1 = ctx.saved_tensors
         g = g.contiguous()
         g2 = _flat2d(g)
-        # [M, r] data gradient through W2 and the ReLU in one kernel (the ReLU mask is the GEMM's epilogue)
-        dpre = ops.gemm_nt(g2, weight_t(w2), None, _lib.EPI_RELU_BWD, residual=_flat2d(h1))
         do = None
-        if ctx.needs_input_grad[0]:
-            do = ops.gemm_nt(dpre, weight_t(w1), residual=g2).view(o.shape)  # + identity branch
+        if ops.adapter_supported(w1.size(1), w1.size(0)):
+            do, dpre = ops.adapter_bwd_dx(g2, weight_t(w2), weight_t(w1), _flat2d(h1))
+            do = do.view(o.shape)
+        else:
+            # [M, r] data gradient through W2 and the ReLU in one kernel (the ReLU mask is the GEMM's epilogue)
+            dpre = ops.gemm_nt(g2, weight_t(w2), None, _lib.EPI_RELU_BWD, residual=_flat2d(h1))
+            if ctx.needs_input_grad[0]:
+                do = ops.gemm_nt(dpre, weight_t(w1), residual=g2).view(o.shape)  # + identity branch
         dw1, db1 = _wgrad_bias(dpre, _flat2d(o), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         dw2, db2 = _wgrad_bias(g2, _flat2d(h1), ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         return do, dw1, db1, dw2, db2

@@ -302,6 +302,36 @@ def gemm_tn(a, b, with_colsum=False):
     return (c, cs) if with_colsum else c
 
 
+# ---------------------------------------------------------------------------- adapter (one kernel per direction)
+def adapter_supported(h, r):
+    return bool(get_lib().mm_adapter_supported(h, r))
+
+
+def adapter_fwd(o, w1, b1, w2, b2):
+    """out = o + relu(o W1^T + b1) W2^T + b2; returns (out, h1) with h1 the saved ReLU output [rows, r]."""
+    _need_cuda(o, w1, b1, w2, b2)
+    h, r = w1.size(1), w1.size(0)
+    o2 = o.contiguous().view(-1, h)
+    out = torch.empty_like(o2)
+    h1 = torch.empty(o2.size(0), r, dtype=o.dtype, device=o.device)
+    check(get_lib().mm_adapter_fwd(out.data_ptr(), h1.data_ptr(), o2.data_ptr(), w1.contiguous().data_ptr(), b1.data_ptr(),
+                                   w2.contiguous().data_ptr(), b2.data_ptr(), o2.size(0), h, r, dtype_code(o.dtype), _stream()),
+          "adapter_fwd")
+    return out.view(o.shape), h1
+
+
+def adapter_bwd_dx(dy, w2t, w1t, h1):
+    """(dx, dpre) of the adapter: dpre = (dy W2) * (h1 > 0), dx = dy + dpre W1; w2t = W2^T [r, h], w1t = W1^T [h, r]."""
+    _need_cuda(dy, w2t, w1t, h1)
+    r, h = w2t.shape
+    dy2 = dy.contiguous().view(-1, h)
+    dx = torch.empty_like(dy2)
+    dpre = torch.empty(dy2.size(0), r, dtype=dy.dtype, device=dy.device)
+    check(get_lib().mm_adapter_bwd_dx(dx.data_ptr(), dpre.data_ptr(), dy2.data_ptr(), w2t.data_ptr(), w1t.data_ptr(),
+                                      h1.data_ptr(), dy2.size(0), h, r, dtype_code(dy.dtype), _stream()), "adapter_bwd_dx")
+    return dx, dpre
+
+
 # ---------------------------------------------------------------------------- attention
 def attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask=None):
     """qkv: contiguous [s, b, np, 3*hn] (post-rotary).  mask None => implicit causal; otherwise a

@@ -486,3 +486,33 @@ def test_gemm_nt_backward_epilogues(ops, cuda_device, force_gemm256, dt, M, N, K
         assert torch.equal(got, want)
     else:
         ulp_close(got, want.float(), dtype, ulps=2, atol=1e-3)  # generic kernel vs fp64 autograd: fast-tanh cancellation near 0
+
+
+# ------------------------------------------------------------------ fused adapter
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("rows,h,r", [(8192, 1024, 128), (100, 1024, 128), (32, 512, 64), (1000, 512, 64)])
+def test_adapter_fused_equals_gemm_chain(ops, cuda_device, dt, rows, h, r):
+    """One-kernel adapter forward / data-gradient == the same chain built from gemm_nt (which test_gemm_nt* and the layer
+    tests pin to the reference): same rounding points and the same K order per element, so bit-identical."""
+    from multimodal_amd import _lib
+    assert ops.adapter_supported(h, r) and not ops.adapter_supported(h, r * 2)
+    torch.manual_seed(rows + h)
+    dtype = DT[dt]
+    mk = lambda *s, sc=1.0: (torch.randn(*s) * sc).to(dtype).to(cuda_device)
+    o, g = mk(rows, h), mk(rows, h)
+    w1, b1, w2, b2 = mk(r, h, sc=h ** -0.5), mk(r), mk(h, r, sc=r ** -0.5), mk(h)
+    out, h1 = ops.adapter_fwd(o, w1, b1, w2, b2)
+    h1_ref = ops.gemm_nt(o, w1, b1, _lib.EPI_BIAS_RELU)
+    out_ref = ops.gemm_nt(h1_ref, w2, b2, _lib.EPI_BIAS, residual=o)
+    assert torch.equal(h1, h1_ref) and torch.equal(out, out_ref)
+    w2t, w1t = ops.transpose2d(w2), ops.transpose2d(w1)
+    dx, dpre = ops.adapter_bwd_dx(g, w2t, w1t, h1)
+    dpre_ref = ops.gemm_nt(g, w2t, None, _lib.EPI_RELU_BWD, residual=h1)
+    dx_ref = ops.gemm_nt(dpre_ref, w1t, residual=g)
+    assert torch.equal(dpre, dpre_ref) and torch.equal(dx, dx_ref)
+    # and against plain fp64 math, so the chain itself is not the only witness
+    o64 = o.double().cpu()
+    h64 = torch.relu((o64 @ w1.double().cpu().t() + b1.double().cpu()).to(dtype).double())
+    ref = o64 + h64 @ w2.double().cpu().t() + b2.double().cpu()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert ((out.double().cpu() - ref).abs() <= 4 * eps * ref.abs() + 4 * eps).all()

@@ -97,8 +97,24 @@ def bench_small():
         print("%-20s %8.1f us %7.2f TB/s" % (name, t, nbytes / t / 1e6))
 
 
+def bench_adapter():
+    r = H // 8
+    o, g = rnd(T, H), rnd(T, H)
+    w1, b1, w2, b2 = rnd(r, H, scale=0.03), rnd(r), rnd(H, r, scale=0.1), rnd(H)
+    t = timeit(lambda: ops.adapter_fwd(o, w1, b1, w2, b2))
+    print("adapter_fwd    %8.1f us  (%.2f TB/s of o+out+h1)" % (t, (2 * T * H * 2 + T * r * 2) / t / 1e6))
+    _, h1 = ops.adapter_fwd(o, w1, b1, w2, b2)
+    w2t, w1t = ops.transpose2d(w2), ops.transpose2d(w1)
+    t = timeit(lambda: ops.adapter_bwd_dx(g, w2t, w1t, h1))
+    print("adapter_bwd_dx %8.1f us" % t)
+    t = timeit(lambda: (ops.gemm_tn(g, h1, with_colsum=True), ops.gemm_tn(h1, o, with_colsum=True)))
+    print("adapter dW x2  %8.1f us" % t)
+    t = timeit(lambda: (ops.transpose2d(w2), ops.transpose2d(w1)))
+    print("transposes x2  %8.1f us" % t)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attn", "gemm", "tn", "small"]
+    which = sys.argv[1:] or ["attn", "gemm", "tn", "small", "adapter"]
     print("device:", torch.cuda.get_device_name(0))
     for w in which:
-        {"attn": bench_attn, "gemm": bench_gemm, "tn": bench_tn, "small": bench_small}[w]()
+        {"attn": bench_attn, "gemm": bench_gemm, "tn": bench_tn, "small": bench_small, "adapter": bench_adapter}[w]()
