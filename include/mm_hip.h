@@ -149,6 +149,13 @@ int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bia
 int mm_gemm_tn_splits(int M, int N, int Kp);
 int mm_gemm_tn(void* C, void* a_colsum, float* workspace, const void* A, const void* B, int M, int N, int Kp, int lda,
                int ldb, int ldc, int splits, int dtype, void* stream);
+/* Two weight gradients over the same M tokens in one launch pair (a linear pair such as the adapter's has two small
+ * ones: together they fill the chip).  Contiguous operands (lda = N, ldb = ldc = Kp).  workspace: fp32
+ * [splits, N0*Kp0 + N0 + N1*Kp1 + N1] with splits = mm_gemm_tn_pair_splits(...) (0 = not a supported shape). */
+int mm_gemm_tn_pair_splits(int M, int N0, int Kp0, int N1, int Kp1);
+int mm_gemm_tn_pair(void* C0, void* a_colsum0, const void* A0, const void* B0, int N0, int Kp0, void* C1, void* a_colsum1,
+                    const void* A1, const void* B1, int N1, int Kp1, int M, float* workspace, int splits, int dtype,
+                    void* stream);
 
 /* ------------------------------------------------------------------ MAGMA adapter, one kernel per direction
  * Replaces Adapter.forward and its backward (megatron/model/adapter.py:18-25,109-117):

@@ -36,16 +36,32 @@ template <typename T> struct Ones;
 template <> struct Ones<BF16> { static __device__ __forceinline__ bf16x8 get() { const __bf16 o = (__bf16)1.0f; return bf16x8{o, o, o, o, o, o, o, o}; } };
 template <> struct Ones<F16> { static __device__ __forceinline__ f16x8 get() { const _Float16 o = (_Float16)1.0f; return f16x8{o, o, o, o, o, o, o, o}; } };
 
-// SLAB: fp32 partials to ws [gridDim.y][N*Kp (+ N column sums when CS)]; otherwise direct 16-bit output.
-template <typename T, bool SLAB, bool CS>
-__global__ __launch_bounds__(256) void gemm_tn_k(u16* __restrict__ C, u16* __restrict__ colsum, float* __restrict__ ws,
-                                                 const u16* __restrict__ A, const u16* __restrict__ B, int M, int N, int Kp,
-                                                 int lda, int ldb, int ldc, int tiles_k, int rows_per_split) {
+// One weight-gradient problem.  Two of them can share a launch (mm_gemm_tn_pair): a linear layer pair such as the
+// adapter's has two small weight gradients over the same tokens, and one grid of 256 workgroups covers both.
+struct TnProb {
+    u16* C;          // [N, Kp] output (ldc)
+    u16* colsum;     // [N] column sums of A, or null
+    const u16* A;    // [M, N]  (lda)
+    const u16* B;    // [M, Kp] (ldb)
+    int N, Kp, lda, ldb, ldc, tiles_k, tiles;
+    size_t ws_off;   // offset of this problem's part inside one split's workspace slab (floats)
+};
+
+// SLAB: fp32 partials to ws [gridDim.y][slab] (slab = both problems' N*Kp (+ N column sums)); otherwise direct 16-bit output.
+template <typename T, bool SLAB>
+__global__ __launch_bounds__(256) void gemm_tn_k(TnProb p0, TnProb p1, float* __restrict__ ws, size_t slab, int rows_per_split) {
     typedef Tile<128> TL;
     typedef typename M32<T>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES];  // [buf][A | B]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const bool second = (int)blockIdx.x >= p0.tiles;  // workgroup-uniform
+    const TnProb& P = second ? p1 : p0;
+    const int tile = second ? (int)blockIdx.x - p0.tiles : (int)blockIdx.x;
+    const u16* __restrict__ A = P.A;
+    const u16* __restrict__ B = P.B;
+    const int N = P.N, Kp = P.Kp, lda = P.lda, ldb = P.ldb, ldc = P.ldc, tiles_k = P.tiles_k;
+    const bool CS = P.colsum != nullptr;
+    const int tn = tile / tiles_k, tk = tile % tiles_k;
     const int n0 = tn * TN_BT, k0 = tk * TN_BT;
     const int m_begin = blockIdx.y * rows_per_split;
     const int ntile = rows_per_split / 64;
@@ -59,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_tn_k(u16* __restrict__ C, u16* __res
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const bool do_cs = CS && tk == 0 && wc == 0;  // wave-uniform
+    const bool do_cs = CS && tk == 0 && wc == 0;  // wave-uniform (CS: this problem wants column sums)
     f32x16 cs[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -107,7 +123,8 @@ __global__ __launch_bounds__(256) void gemm_tn_k(u16* __restrict__ C, u16* __res
         __syncthreads();
     }
     // D[row = n (registers)][col = kp (lane)]
-    const size_t slab = (size_t)N * Kp + (CS ? N : 0);
+    float* wsp = ws + (size_t)blockIdx.y * slab + P.ws_off;
+    u16* C = P.C;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_tn_k(u16* __restrict__ C, u16* __res
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wr * 64 + 32 * i + acc_row(e, hh);
-                if (SLAB) ws[(size_t)blockIdx.y * slab + (size_t)n * Kp + kp] = acc[i][j][e];
+                if (SLAB) wsp[(size_t)n * Kp + kp] = acc[i][j][e];
                 else C[(size_t)n * ldc + kp] = from_f32<T>(acc[i][j][e]);
             }
         }
@@ -126,17 +143,15 @@ __global__ __launch_bounds__(256) void gemm_tn_k(u16* __restrict__ C, u16* __res
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wr * 64 + 32 * i + acc_row(e, hh);
-                if (SLAB) ws[(size_t)blockIdx.y * slab + (size_t)N * Kp + n] = cs[i][e];
-                else colsum[n] = from_f32<T>(cs[i][e]);
+                if (SLAB) wsp[(size_t)N * Kp + n] = cs[i][e];
+                else P.colsum[n] = from_f32<T>(cs[i][e]);
             }
     }
 }
 
-// C[n, kp] = sum_s ws[s][n][kp] (fixed order), 4 elements per thread; elements past N*Kp are the column sums
+// out = sum_s ws[s][.] (fixed order), 4 elements per thread; a slab is [p0: N*Kp, N column sums | p1: the same]
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_k(u16* __restrict__ C, u16* __restrict__ colsum, const float* __restrict__ ws,
-                                                       int N, int Kp, int ldc, int splits, int ncs) {
-    const size_t nk = (size_t)N * Kp, slab = nk + ncs;
+__global__ __launch_bounds__(256) void splitk_reduce_k(TnProb p0, TnProb p1, const float* __restrict__ ws, size_t slab, int splits) {
     const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= slab) return;
     f32x4 s = *reinterpret_cast<const f32x4*>(ws + i4);
@@ -144,60 +159,100 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(u16* __restrict__ C, u16*
         const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)k * slab + i4);
         s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
+    const bool second = p1.tiles > 0 && i4 >= p1.ws_off;
+    const TnProb& P = second ? p1 : p0;
+    const size_t j = i4 - P.ws_off, nk = (size_t)P.N * P.Kp;
     u16* o;
-    if (i4 < nk) {
-        const int n = (int)(i4 / Kp), kp = (int)(i4 % Kp);
-        o = C + (size_t)n * ldc + kp;
-    } else {
-        o = colsum + (i4 - nk);
-    }
+    if (j < nk) o = P.C + (j / P.Kp) * P.ldc + (j % P.Kp);
+    else o = P.colsum + (j - nk);
     *reinterpret_cast<u32x2*>(o) = u32x2{(uint32_t)from_f32<T>(s[0]) | ((uint32_t)from_f32<T>(s[1]) << 16),
                                         (uint32_t)from_f32<T>(s[2]) | ((uint32_t)from_f32<T>(s[3]) << 16)};
+}
+
+static int tn_check(const char* fn, const void* C, const void* cs, const void* A, const void* B, int M, int N, int Kp, int lda, int ldb,
+                    int ldc, int splits) {
+    MM_CHECK_ARG(C && A && B, "%s: null pointer", fn);
+    MM_CHECK_ARG(M > 0 && N > 0 && Kp > 0, "%s: M=%d N=%d Kp=%d must be positive", fn, M, N, Kp);
+    MM_CHECK_ARG(N % TN_BT == 0 && Kp % TN_BT == 0, "%s: N=%d and Kp=%d must be multiples of %d", fn, N, Kp, TN_BT);
+    MM_CHECK_ARG(splits >= 1 && splits <= 65535 && M % (64 * splits) == 0, "%s: M=%d must be a multiple of 64*splits (splits=%d)", fn, M, splits);
+    MM_CHECK_ARG(lda >= N && ldb >= Kp && ldc >= Kp && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0,
+                 "%s: bad leading dimensions lda=%d ldb=%d ldc=%d", fn, lda, ldb, ldc);
+    MM_CHECK_ARG(aligned16(A) && aligned16(B) && (((uintptr_t)C) & 7) == 0 && (((uintptr_t)cs) & 7) == 0,
+                 "%s: A/B must be 16-byte, C/a_colsum 8-byte aligned", fn);
+    return MM_OK;
+}
+
+static TnProb tn_prob(void* C, void* cs, const void* A, const void* B, int N, int Kp, int lda, int ldb, int ldc, size_t ws_off) {
+    TnProb p;
+    p.C = (u16*)C; p.colsum = (u16*)cs; p.A = (const u16*)A; p.B = (const u16*)B;
+    p.N = N; p.Kp = Kp; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.tiles_k = Kp / TN_BT; p.tiles = (N / TN_BT) * p.tiles_k; p.ws_off = ws_off;
+    return p;
+}
+
+template <typename T>
+static int tn_launch(const TnProb& p0, const TnProb& p1, float* ws, size_t slab, int M, int splits, hipStream_t st) {
+    dim3 grid(p0.tiles + p1.tiles, splits), block(256);
+    if (splits == 1) {
+        gemm_tn_k<T, false><<<grid, block, 0, st>>>(p0, p1, nullptr, 0, M);
+        MM_CHECK_LAUNCH();
+    } else {
+        gemm_tn_k<T, true><<<grid, block, 0, st>>>(p0, p1, ws, slab, M / splits);
+        MM_CHECK_LAUNCH();
+        splitk_reduce_k<T><<<(unsigned)((slab / 4 + 255) / 256), 256, 0, st>>>(p0, p1, ws, slab, splits);
+        MM_CHECK_LAUNCH();
+    }
+    return MM_OK;
 }
 
 }  // namespace mm
 
 using namespace mm;
 
-extern "C" int mm_gemm_tn_splits(int M, int N, int Kp) {
-    if (M <= 0 || N <= 0 || Kp <= 0 || N % TN_BT || Kp % TN_BT || M % 64) return 0;  // 0: shape not supported by this kernel
-    const int tiles = (N / TN_BT) * (Kp / TN_BT);
+static int tn_splits_for(int M, int tiles) {
     int splits = 1;
     while (tiles * splits * 2 <= 256 && M % (64 * splits * 2) == 0 && M / (splits * 2) >= 128) splits *= 2;
     return splits;
 }
 
+extern "C" int mm_gemm_tn_splits(int M, int N, int Kp) {
+    if (M <= 0 || N <= 0 || Kp <= 0 || N % TN_BT || Kp % TN_BT || M % 64) return 0;  // 0: shape not supported by this kernel
+    return tn_splits_for(M, (N / TN_BT) * (Kp / TN_BT));
+}
+
+extern "C" int mm_gemm_tn_pair_splits(int M, int N0, int Kp0, int N1, int Kp1) {
+    if (M <= 0 || N0 <= 0 || Kp0 <= 0 || N1 <= 0 || Kp1 <= 0 || N0 % TN_BT || Kp0 % TN_BT || N1 % TN_BT || Kp1 % TN_BT || M % 64) return 0;
+    return tn_splits_for(M, (N0 / TN_BT) * (Kp0 / TN_BT) + (N1 / TN_BT) * (Kp1 / TN_BT));
+}
+
 extern "C" int mm_gemm_tn(void* C, void* a_colsum, float* workspace, const void* A, const void* B, int M, int N, int Kp, int lda,
                           int ldb, int ldc, int splits, int dtype, void* stream) {
-    MM_CHECK_ARG(C && A && B, "mm_gemm_tn: null pointer");
-    MM_CHECK_ARG(M > 0 && N > 0 && Kp > 0, "mm_gemm_tn: M=%d N=%d Kp=%d must be positive", M, N, Kp);
-    MM_CHECK_ARG(N % TN_BT == 0 && Kp % TN_BT == 0, "mm_gemm_tn: N=%d and Kp=%d must be multiples of %d", N, Kp, TN_BT);
-    MM_CHECK_ARG(splits >= 1 && M % (64 * splits) == 0, "mm_gemm_tn: M=%d must be a multiple of 64*splits (splits=%d)", M, splits);
-    MM_CHECK_ARG(lda >= N && ldb >= Kp && ldc >= Kp && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0,
-                 "mm_gemm_tn: bad leading dimensions lda=%d ldb=%d ldc=%d", lda, ldb, ldc);
-    MM_CHECK_ARG(aligned16(A) && aligned16(B) && (((uintptr_t)C) & 7) == 0 && (((uintptr_t)a_colsum) & 7) == 0,
-                 "mm_gemm_tn: A/B must be 16-byte, C/a_colsum 8-byte aligned");
+    if (int rc = tn_check("mm_gemm_tn", C, a_colsum, A, B, M, N, Kp, lda, ldb, ldc, splits)) return rc;
     MM_CHECK_ARG(splits == 1 || (workspace && aligned16(workspace)),
                  "mm_gemm_tn: splits > 1 needs a 16-byte aligned fp32 workspace [splits, N*Kp + N]");
-    MM_CHECK_ARG(splits <= 65535, "mm_gemm_tn: too many splits");
-    hipStream_t st = (hipStream_t)stream;
-    const int tiles_k = Kp / TN_BT;
-    dim3 grid((N / TN_BT) * tiles_k, splits), block(256);
+    const TnProb p0 = tn_prob(C, a_colsum, A, B, N, Kp, lda, ldb, ldc, 0);
+    TnProb p1 = p0;
+    p1.tiles = 0;
+    const size_t slab = (size_t)N * Kp + (a_colsum ? N : 0);
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
-        u16* cs = (u16*)a_colsum;
-        if (splits == 1) {
-            if (cs) gemm_tn_k<T, false, true><<<grid, block, 0, st>>>((u16*)C, cs, nullptr, (const u16*)A, (const u16*)B, M, N, Kp, lda, ldb, ldc, tiles_k, M);
-            else gemm_tn_k<T, false, false><<<grid, block, 0, st>>>((u16*)C, nullptr, nullptr, (const u16*)A, (const u16*)B, M, N, Kp, lda, ldb, ldc, tiles_k, M);
-            MM_CHECK_LAUNCH();
-        } else {
-            if (cs) gemm_tn_k<T, true, true><<<grid, block, 0, st>>>((u16*)C, cs, workspace, (const u16*)A, (const u16*)B, M, N, Kp, lda, ldb, ldc, tiles_k, M / splits);
-            else gemm_tn_k<T, true, false><<<grid, block, 0, st>>>((u16*)C, nullptr, workspace, (const u16*)A, (const u16*)B, M, N, Kp, lda, ldb, ldc, tiles_k, M / splits);
-            MM_CHECK_LAUNCH();
-            const size_t slab = (size_t)N * Kp + (cs ? N : 0);
-            splitk_reduce_k<T><<<(unsigned)((slab / 4 + 255) / 256), 256, 0, st>>>((u16*)C, cs, workspace, N, Kp, ldc, splits, cs ? N : 0);
-            MM_CHECK_LAUNCH();
-        }
-        return (int)MM_OK;
+        return tn_launch<T>(p0, p1, workspace, slab, M, splits, (hipStream_t)stream);
+    });
+}
+
+extern "C" int mm_gemm_tn_pair(void* C0, void* a_colsum0, const void* A0, const void* B0, int N0, int Kp0, void* C1,
+                               void* a_colsum1, const void* A1, const void* B1, int N1, int Kp1, int M, float* workspace,
+                               int splits, int dtype, void* stream) {
+    if (int rc = tn_check("mm_gemm_tn_pair", C0, a_colsum0, A0, B0, M, N0, Kp0, N0, Kp0, Kp0, splits)) return rc;
+    if (int rc = tn_check("mm_gemm_tn_pair", C1, a_colsum1, A1, B1, M, N1, Kp1, N1, Kp1, Kp1, splits)) return rc;
+    MM_CHECK_ARG(splits == 1 || (workspace && aligned16(workspace)),
+                 "mm_gemm_tn_pair: splits > 1 needs a 16-byte aligned fp32 workspace [splits, N0*Kp0 + N0 + N1*Kp1 + N1]");
+    const size_t slab0 = (size_t)N0 * Kp0 + (a_colsum0 ? N0 : 0);
+    const size_t slab = slab0 + (size_t)N1 * Kp1 + (a_colsum1 ? N1 : 0);
+    const TnProb p0 = tn_prob(C0, a_colsum0, A0, B0, N0, Kp0, N0, Kp0, Kp0, 0);
+    const TnProb p1 = tn_prob(C1, a_colsum1, A1, B1, N1, Kp1, N1, Kp1, Kp1, slab0);
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        return tn_launch<T>(p0, p1, workspace, slab, M, splits, (hipStream_t)stream);
     });
 }

@@ -160,8 +160,11 @@ class AdapterFn(torch.autograd.Function):
             dpre = ops.gemm_nt(g2, weight_t(w2), None, _lib.EPI_RELU_BWD, residual=_flat2d(h1))
             if ctx.needs_input_grad[0]:
                 do = ops.gemm_nt(dpre, weight_t(w1), residual=g2).view(o.shape)  # + identity branch
-        dw1, db1 = _wgrad_bias(dpre, _flat2d(o), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        dw2, db2 = _wgrad_bias(g2, _flat2d(h1), ctx.needs_input_grad[3], ctx.needs_input_grad[4])
+        if all(ctx.needs_input_grad[1:5]):  # both weight gradients and both bias gradients: one launch pair
+            dw1, db1, dw2, db2 = ops.gemm_tn_pair(dpre, _flat2d(o), g2, _flat2d(h1))
+        else:
+            dw1, db1 = _wgrad_bias(dpre, _flat2d(o), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+            dw2, db2 = _wgrad_bias(g2, _flat2d(h1), ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         return do, dw1, db1, dw2, db2
 
 

@@ -302,6 +302,29 @@ def gemm_tn(a, b, with_colsum=False):
     return (c, cs) if with_colsum else c
 
 
+def gemm_tn_pair(a0, b0, a1, b1):
+    """(A0^T B0, colsum A0, A1^T B1, colsum A1) for two operand pairs over the same rows, in one launch pair."""
+    _need_cuda(a0, b0, a1, b1)
+    a0, b0, a1, b1 = a0.contiguous(), b0.contiguous(), a1.contiguous(), b1.contiguous()
+    M = a0.size(0)
+    if not (b0.size(0) == M and a1.size(0) == M and b1.size(0) == M):
+        raise RuntimeError("gemm_tn_pair: row counts differ")
+    lib = get_lib()
+    N0, K0, N1, K1 = a0.size(1), b0.size(1), a1.size(1), b1.size(1)
+    splits = lib.mm_gemm_tn_pair_splits(M, N0, K0, N1, K1)
+    if splits == 0:
+        c0, s0 = gemm_tn(a0, b0, with_colsum=True)
+        c1, s1 = gemm_tn(a1, b1, with_colsum=True)
+        return c0, s0, c1, s1
+    mk = lambda *sh: torch.empty(*sh, dtype=a0.dtype, device=a0.device)
+    c0, s0, c1, s1 = mk(N0, K0), mk(N0), mk(N1, K1), mk(N1)
+    ws = torch.empty(splits * (N0 * K0 + N0 + N1 * K1 + N1), dtype=torch.float32, device=a0.device) if splits > 1 else None
+    check(lib.mm_gemm_tn_pair(c0.data_ptr(), s0.data_ptr(), a0.data_ptr(), b0.data_ptr(), N0, K0, c1.data_ptr(), s1.data_ptr(),
+                              a1.data_ptr(), b1.data_ptr(), N1, K1, M, _ptr(ws), splits, dtype_code(a0.dtype), _stream()),
+          "gemm_tn_pair")
+    return c0, s0, c1, s1
+
+
 # ---------------------------------------------------------------------------- adapter (one kernel per direction)
 def adapter_supported(h, r):
     return bool(get_lib().mm_adapter_supported(h, r))

@@ -516,3 +516,27 @@ def test_adapter_fused_equals_gemm_chain(ops, cuda_device, dt, rows, h, r):
     ref = o64 + h64 @ w2.double().cpu().t() + b2.double().cpu()
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     assert ((out.double().cpu() - ref).abs() <= 4 * eps * ref.abs() + 4 * eps).all()
+
+
+@pytest.mark.parametrize("M,h,r", [(8192, 1024, 128), (512, 256, 128), (192, 128, 128), (100, 128, 128)])
+def test_gemm_tn_pair_equals_two_calls(ops, cuda_device, M, h, r):
+    """Both adapter weight gradients + both bias gradients from one launch pair.  Different split counts change the fp32
+    summation order, so compare with the fp64 reference at the single-call tolerance; at equal split counts the results
+    must be bit-identical to the separate calls."""
+    from multimodal_amd._lib import get_lib
+    torch.manual_seed(M + h)
+    mk = lambda *s, sc=1.0: (torch.randn(*s) * sc).bfloat16().to(cuda_device)
+    dpre, o, g, h1 = mk(M, r), mk(M, h, sc=M ** -0.5), mk(M, h), mk(M, r, sc=M ** -0.5)
+    c0, s0, c1, s1 = ops.gemm_tn_pair(dpre, o, g, h1)
+    eps = 2.0 ** -8
+    for got, a, b in ((c0, dpre, o), (c1, g, h1)):
+        ref = a.double().cpu().t() @ b.double().cpu()
+        assert ((got.double().cpu() - ref).abs() <= 2 * eps * ref.abs() + 1e-3).all()
+    for got, a in ((s0, dpre), (s1, g)):
+        ref = a.double().cpu().sum(0)
+        assert ((got.double().cpu() - ref).abs() <= 2 * eps * ref.abs() + 0.1 * eps * a.double().cpu().abs().sum(0) + 1e-3).all()
+    lib = get_lib()
+    if M % 64 == 0 and lib.mm_gemm_tn_pair_splits(M, r, h, h, r) == lib.mm_gemm_tn_splits(M, r, h) == lib.mm_gemm_tn_splits(M, h, r):
+        d0, t0 = ops.gemm_tn(dpre, o, with_colsum=True)
+        d1, t1 = ops.gemm_tn(g, h1, with_colsum=True)
+        assert torch.equal(c0, d0) and torch.equal(s0, t0) and torch.equal(c1, d1) and torch.equal(s1, t1)
