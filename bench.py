@@ -55,7 +55,17 @@ def roofline_from_probe(cfg, probe):
             "achieved": round(achieved, 2), "peak": PEAK_BF16_FLOPS / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), "avg_kernel_ms": round(avg_ms, 4),
             "median_kernel_ms": round(ms[len(ms) // 2], 4), "launches_timed": len(ms), "flops_per_launch": flops,
-            "traffic": None}
+            "traffic": pmc_traffic("gemm_nt_256_k<bf16, bias_gelu> M=%d N=%d K=%d" % (T, 4 * h, h))}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE x2 (gfx950 correction) +
+    WRITE_SIZE, collected with rocprofv3 --pmc in separate runs of this same script); None when not collected for this shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)[kernel]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(cfg, budget_s):
