@@ -12,3 +12,4 @@ from .mappings import (copy_to_model_parallel_region, gather_from_model_parallel
 from .random import checkpoint, get_cuda_rng_tracker, model_parallel_cuda_manual_seed  # noqa: F401
 from .utils import VocabUtility, divide, ensure_divisibility, split_tensor_along_last_dim  # noqa: F401
 from .data_parallel import allreduce_gradients  # noqa: F401
+from .cross_entropy import vocab_parallel_cross_entropy  # noqa: F401

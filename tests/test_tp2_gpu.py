@@ -105,3 +105,59 @@ def _free_port_shared():
     if _PORT is None:
         _PORT = _free_port()
     return _PORT
+
+
+def _ce_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from multimodal_amd import mpu
+    mpu.initialize_model_parallel(2, fp32_allreduce=True)
+    fails = []
+    try:
+        T, V = 96, 2048
+        g = torch.Generator().manual_seed(11)
+        logits = (torch.randn(T, V, generator=g) * 3).bfloat16()
+        target = torch.randint(0, V, (T,), generator=g)
+        target[0], target[1] = 0, V - 1                      # partition edges
+        gout = torch.rand(T, generator=g)
+        vp = V // world
+        mine = logits[:, rank * vp:(rank + 1) * vp].contiguous().to(dev).requires_grad_(True)
+        loss = mpu.vocab_parallel_cross_entropy(mine, target.to(dev))
+        loss.backward(gout.to(dev))
+        x = logits.double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(x, target, reduction="none")   # == the reference's formula
+        ref.backward(gout.double())
+        if not torch.allclose(loss.double().cpu(), ref.detach(), rtol=1e-5, atol=1e-5):
+            fails.append(f"rank {rank}: loss max err {(loss.double().cpu() - ref.detach()).abs().max().item():.3g}")
+        gref = x.grad[:, rank * vp:(rank + 1) * vp]
+        err = (mine.grad.double().cpu() - gref).abs().max().item()
+        if err > 2.0 ** -8 * gref.abs().max().item() + 1e-6:
+            fails.append(f"rank {rank}: dlogits max err {err:.3g}")
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        fails.append(f"rank {rank}: {type(e).__name__}: {e}\n{traceback.format_exc()}")
+    q.put((rank, fails))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_tp2_vocab_parallel_cross_entropy(cuda_device):
+    """mpu.vocab_parallel_cross_entropy over two vocabulary partitions (two processes, gloo) == full-vocabulary cross
+    entropy (the reference's formula, megatron/mpu/cross_entropy.py:27-112) for the loss and for each rank's d logits."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=100) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    fails = [f for _, fl in results for f in fl]
+    assert not fails, "\n".join(fails)
