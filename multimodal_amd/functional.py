@@ -214,6 +214,32 @@ class DualLayerNormFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class DualLayerNormResFn(torch.autograd.Function):
+    """DualLayerNormFn that also hands x back for the residual branch, so that the residual's gradient arrives HERE and is
+    added inside the LayerNorm backward kernel (fp32, one rounding) instead of by a separate autograd accumulation pass
+    over [T, h]."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, eps):
+        y1, y2, mean, rstd = ops.layernorm_fwd(x, w1, b1, eps, w2, b2)
+        ctx.save_for_backward(x, w1, w2, mean, rstd)
+        return y1, y2, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy1, dy2, dres):
+        x, w1, w2, mean, rstd = ctx.saved_tensors
+        need_p = any(ctx.needs_input_grad[1:5])
+        dx, grads = ops.layernorm_bwd(dy1, x, w1, mean, rstd, dy2=dy2, w2=w2, dresidual=dres, param_grads=need_p)
+        if need_p:
+            return dx, grads[0], grads[1], grads[2], grads[3], None
+        return dx, None, None, None, None, None
+
+
+def dual_layer_norm_res(x, w1, b1, w2, b2, eps):
+    """(LN1(x), LN2(x), x): use the returned x for the residual add."""
+    return DualLayerNormResFn.apply(x, w1, b1, w2, b2, eps)
+
+
 def dual_layer_norm(x, w1, b1, w2, b2, eps):
     return DualLayerNormFn.apply(x, w1, b1, w2, b2, eps)
 

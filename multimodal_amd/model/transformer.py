@@ -178,7 +178,8 @@ class ParallelTransformerLayer(nn.Module):
             if self.gpt_j_tied:
                 x1 = x2 = ln1(x)
             elif isinstance(ln1, LayerNorm) and isinstance(ln2, LayerNorm) and ln1.eps == ln2.eps:
-                x1, x2 = Fn.dual_layer_norm(x, ln1.weight, ln1.bias, ln2.weight, ln2.bias, ln1.eps)
+                # the residual is routed through the same node: its gradient is added inside the LayerNorm backward kernel
+                x1, x2, residual = Fn.dual_layer_norm_res(x, ln1.weight, ln1.bias, ln2.weight, ln2.bias, ln1.eps)
             else:
                 x1, x2 = ln1(x), ln2(x)
             attention_output, attention_bias = self.attention(x1, attention_mask, layer_past=layer_past)
