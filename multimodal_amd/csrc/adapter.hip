@@ -13,12 +13,13 @@
 // so one kernel template serves both.  Structure: a workgroup owns 32 token rows (256 workgroups at 8192 tokens);
 //   * the 32 x h block of X is staged ONCE into LDS (XOR-swizzled 16-byte chunks) - it is the MFMA operand of the first
 //     product AND the residual of the second, and the output block is assembled in place and stored with full-line writes;
-//   * the weights (2 x 256 KiB, L2-resident, shared by every workgroup) stream through a two-buffer LDS ring in 24 steps
-//     (16 K-tiles of Wa, 8 column chunks of Wb), fetched with COALESCED 16-byte loads into registers several steps ahead
+//   * the weights (2 x 256 KiB, L2-resident, shared by every workgroup) stream through a three-buffer LDS ring in 32 steps
+//     (16 K-tiles of Wa, 16 column chunks of Wb), fetched with COALESCED 16-byte loads into registers several steps ahead
 //     (fully unrolled, so the prefetch distance is just register liveness) - fragment-shaped loads straight from global
 //     memory were tried first and are 8x more L1 accesses per instruction (one line per lane): 26 us, L1-issue-bound;
 //   * H goes through an 8 KiB LDS tile between the two products (and to HBM once, coalesced: the backward needs it);
-//   * one barrier per step: the write of step s into buffer s&1 is ordered after the reads of step s-2 by barrier s-1.
+//   * one barrier per step; within a step the LDS write of tile s+2 and the fragment reads of tile s+1 overlap the
+//     MFMAs of tile s (one wave per SIMD: software pipelining is the only latency hiding there is).
 // Rounding points are exactly those of the unfused path (mm_gemm_nt with MM_EPI_BIAS_RELU / MM_EPI_BIAS + residual /
 // MM_EPI_RELU_BWD / residual), and each output element's K-order is the same, so the results are bit-identical to it.
 #include "gemm_common.h"
@@ -40,17 +41,18 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
     constexpr int S1 = HID / 64;                    // ... in S1 steps of 64 k (one Wa tile [R][64] each)
     constexpr int CH2 = 64;                         // second product: chunks of CH2 output columns (Wb rows), 16 per wave
     constexpr int S2 = HID / CH2;
+    constexpr int NI2 = CH2 / 64;                   // MFMA tiles per wave per chunk
     constexpr int KS2 = R / 32;
     constexpr int L1N = R * 8 / 256;                // 16-byte loads per thread per Wa tile
     constexpr int L2N = CH2 * HCPR / 256;           // ... per Wb chunk
     constexpr int LMAX = L1N > L2N ? L1N : L2N;
     constexpr int RING = (R * 128 > CH2 * HROW) ? R * 128 : CH2 * HROW;  // bytes per ring buffer
     constexpr int D1 = 8;                           // prefetch distance in steps (Wa tiles and Wb chunks alike): ~128 KiB in flight per CU
-    __shared__ __attribute__((aligned(16))) char smem[AD_BM * XROW + AD_BM * HROW + 2 * RING + HID * 2];
+    __shared__ __attribute__((aligned(16))) char smem[AD_BM * XROW + AD_BM * HROW + 3 * RING + HID * 2];
     char* Xs = smem;
     char* Hs = smem + AD_BM * XROW;
     char* Ws = Hs + AD_BM * HROW;
-    char* Bs = Ws + 2 * RING;  // bb staged once (forward)
+    char* Bs = Ws + 3 * RING;  // bb staged once (forward)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, frow = lane & 15, fq = lane >> 4;
     const int m0 = blockIdx.x * AD_BM;
 
@@ -74,8 +76,9 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
     };
     auto w_store = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        char* buf = Ws + (s & 1) * RING;
-        if constexpr (s < S1) {
+        char* buf = Ws + (s % 3) * RING;
+        if constexpr (s >= S1 + S2) {
+        } else if constexpr (s < S1) {
 #pragma unroll
             for (int i = 0; i < L1N; ++i) {
                 const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
@@ -128,33 +131,63 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
     }
 
     // ---- first product: H[32, R], wave w owns columns [w*R/4, (w+1)*R/4)
+    // Ring protocol (3 buffers): during step s the wave (1) writes the tile of step s+2, (2) reads the FRAGMENTS of step
+    // s+1 into registers, (3) runs the MFMAs of step s on fragments it read one step earlier - with one wave per SIMD
+    // nothing else hides the LDS latency - then one barrier: it publishes the write of (1) and retires the reads of (2),
+    // whose buffer is rewritten in step s+2.
     f32x4 acc1[NI1][2];
 #pragma unroll
     for (int i = 0; i < NI1; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    frag FA[S1][2][2], FB[S1][2][NI1], FB2[S2][KS2][NI2];
+    auto frags1 = [&](auto sc) {  // fragments of first-product step s
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s < S1) {
+            const char* buf = Ws + (s % 3) * RING;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    FA[s][kk][mi] = *reinterpret_cast<const frag*>(Xs + (mi * 16 + frow) * XROW + (((s * 8 + kk * 4 + fq) ^ frow) << 4));
+#pragma unroll
+                for (int ni = 0; ni < NI1; ++ni) {
+                    const int n = nb1 + ni * 16 + frow;
+                    FB[s][kk][ni] = *reinterpret_cast<const frag*>(buf + n * 128 + (((kk * 4 + fq) ^ ((n >> 1) & 7)) << 4));
+                }
+            }
+        }
+    };
+    auto frags2 = [&](auto cc) {  // weight fragments of second-product chunk c
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c < S2) {
+            const char* buf = Ws + ((S1 + c) % 3) * RING;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < NI2; ++ni) {
+                    const int n = wave * (CH2 / 4) + ni * 16 + frow;  // row of the chunk
+                    FB2[c][ks][ni] = *reinterpret_cast<const frag*>(buf + n * HROW + (((ks * 4 + fq) ^ (n & HSW)) << 4));
+                }
+        }
+    };
+    w_store(std::integral_constant<int, 0>{});
+    w_store(std::integral_constant<int, 1>{});
+    __syncthreads();
+    frags1(std::integral_constant<int, 0>{});
     static_for<0, S1>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        w_store(sc);
+        w_store(std::integral_constant<int, s + 2>{});
         static_for<s + D1, s + D1 + 1>([&](auto nx) { w_issue(nx); });  // (a no-op past the last step)
-        __syncthreads();
-        const char* buf = Ws + (s & 1) * RING;
+        frags1(std::integral_constant<int, s + 1>{});
+        if constexpr (s + 1 == S1) frags2(std::integral_constant<int, 0>{});
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            frag fa[2], fb[NI1];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                fa[mi] = *reinterpret_cast<const frag*>(Xs + (mi * 16 + frow) * XROW + (((s * 8 + kk * 4 + fq) ^ frow) << 4));
-#pragma unroll
-            for (int ni = 0; ni < NI1; ++ni) {
-                const int n = nb1 + ni * 16 + frow;
-                fb[ni] = *reinterpret_cast<const frag*>(buf + n * 128 + (((kk * 4 + fq) ^ ((n >> 1) & 7)) << 4));
-            }
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int ni = 0; ni < NI1; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) acc1[ni][mi] = Mfma<T>::run(fb[ni], fa[mi], acc1[ni][mi]);
-        }
+                for (int mi = 0; mi < 2; ++mi) acc1[ni][mi] = Mfma<T>::run(FB[s][kk][ni], FA[s][kk][mi], acc1[ni][mi]);
+        if constexpr (s + 1 < S1) __syncthreads();  // (the last step's barrier comes after the H tile is written)
     });
     // lane holds H[m = mi*16 + frow][n0 .. n0+3], n0 = nb1 + ni*16 + fq*4
 #pragma unroll
@@ -174,30 +207,28 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
         }
     }
 
+    __syncthreads();  // publishes the H tile (and retires the last Wa tile's fragment reads)
+
     // ---- second product: Y[32, HID] = H Wb^T (+ bb) + X in S2 chunks of CH2 columns; wave w owns 16 columns of each chunk
     frag fh[2][KS2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks)
+            fh[mi][ks] = *reinterpret_cast<const frag*>(Hs + (mi * 16 + frow) * HROW + (((ks * 4 + fq) ^ (frow & HSW)) << 4));
+    // H to HBM, 16 bytes per lane, full rows
+#pragma unroll
+    for (int p = 0; p < AD_BM * HCPR / 256; ++p) {
+        const int q = tid + 256 * p, row = q / HCPR, ch = q % HCPR;
+        if (m0 + row < rows)
+            *reinterpret_cast<u32x4*>(Hout + (size_t)(m0 + row) * R + ch * 8) =
+                *reinterpret_cast<const u32x4*>(Hs + row * HROW + ((ch ^ (row & HSW)) << 4));
+    }
     static_for<0, S2>([&](auto cc) {
         constexpr int c = decltype(cc)::value, s = S1 + c;
-        w_store(std::integral_constant<int, s>{});
+        w_store(std::integral_constant<int, s + 2>{});
         static_for<s + D1, s + D1 + 1>([&](auto nx) { w_issue(nx); });
-        __syncthreads();  // (c == 0: also publishes the H tile)
-        if constexpr (c == 0) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ks = 0; ks < KS2; ++ks)
-                    fh[mi][ks] = *reinterpret_cast<const frag*>(Hs + (mi * 16 + frow) * HROW + (((ks * 4 + fq) ^ (frow & HSW)) << 4));
-            // H to HBM, 16 bytes per lane, full rows
-#pragma unroll
-            for (int p = 0; p < AD_BM * HCPR / 256; ++p) {
-                const int q = tid + 256 * p, row = q / HCPR, ch = q % HCPR;
-                if (m0 + row < rows)
-                    *reinterpret_cast<u32x4*>(Hout + (size_t)(m0 + row) * R + ch * 8) =
-                        *reinterpret_cast<const u32x4*>(Hs + row * HROW + ((ch ^ (row & HSW)) << 4));
-            }
-        }
-        const char* buf = Ws + (s & 1) * RING;
-        constexpr int NI2 = CH2 / 64;
+        frags2(std::integral_constant<int, c + 1>{});
         f32x4 acc2[NI2][2];
 #pragma unroll
         for (int i = 0; i < NI2; ++i)
@@ -206,12 +237,9 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
-            for (int ni = 0; ni < NI2; ++ni) {
-                const int n = wave * (CH2 / 4) + ni * 16 + frow;  // row of the chunk
-                const frag fb = *reinterpret_cast<const frag*>(buf + n * HROW + (((ks * 4 + fq) ^ (n & HSW)) << 4));
+            for (int ni = 0; ni < NI2; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) acc2[ni][mi] = Mfma<T>::run(fb, fh[mi][ks], acc2[ni][mi]);
-            }
+                for (int mi = 0; mi < 2; ++mi) acc2[ni][mi] = Mfma<T>::run(FB2[c][ks][ni], fh[mi][ks], acc2[ni][mi]);
 #pragma unroll
         for (int ni = 0; ni < NI2; ++ni) {
             const int n0 = c * CH2 + wave * (CH2 / 4) + ni * 16 + fq * 4;
@@ -231,8 +259,8 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
                             (uint32_t)from_f32<T>(o[2]) | ((uint32_t)from_f32<T>(o[3]) << 16)};
             }
         }
+        __syncthreads();
     });
-    __syncthreads();
 #pragma unroll
     for (int p = 0; p < XPASS; ++p) {
         const int c = tid + 256 * p, row = c / XCPR, ch = c % XCPR;
