@@ -160,14 +160,14 @@ int mm_gemm_tn_pair(void* C0, void* a_colsum0, const void* A0, const void* B0, i
 /* ------------------------------------------------------------------ MAGMA adapter, one kernel per direction
  * Replaces Adapter.forward and its backward (megatron/model/adapter.py:18-25,109-117):
  *   out = o + relu(o W1^T + b1) W2^T + b2,   o/out [rows, h], W1 [r, h], W2 [h, r], h1 = relu(.) [rows, r] (saved).
- * mm_adapter_bwd_dx: dpre = (dy W2) * (h1 > 0) [rows, r],  dx = dy + dpre W1 [rows, h]; w2t = W2^T [r, h] and
- * w1t = W1^T [h, r] contiguous (the weight gradients are mm_gemm_tn(dpre, o) / mm_gemm_tn(dy, h1)).
+ * mm_adapter_bwd_dx: dpre = (dy W2) * (h1 > 0) [rows, r],  dx = dy + dpre W1 [rows, h]; W2 and W1 as stored (the kernel
+ * reads them transposed on chip; the weight gradients are mm_gemm_tn_pair(dpre, o, dy, h1)).
  * Results are bit-identical to the same chain built from mm_gemm_nt.  Fused shapes: mm_adapter_supported(h, r) != 0
  * (currently (1024, 128) and (512, 64)); others return MM_EUNSUPPORTED - compose mm_gemm_nt instead. */
 int mm_adapter_supported(int h, int r);
 int mm_adapter_fwd(void* out, void* h1, const void* o, const void* w1, const void* b1, const void* w2, const void* b2,
                    int rows, int h, int r, int dtype, void* stream);
-int mm_adapter_bwd_dx(void* dx, void* dpre, const void* dy, const void* w2t, const void* w1t, const void* h1, int rows,
+int mm_adapter_bwd_dx(void* dx, void* dpre, const void* dy, const void* w2, const void* w1, const void* h1, int rows,
                       int h, int r, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ fused attention

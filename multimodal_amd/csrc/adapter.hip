@@ -9,6 +9,8 @@
 //
 //   forward :  X = o,  Wa = W1, f1 = relu(. + b1),          Wb = W2,   f2 = . + b2      (H = the saved ReLU output)
 //   backward:  X = dY, Wa = W2^T, f1 = mask by saved H > 0, Wb = W1^T, f2 = identity    (H = d(pre-activation), Y = dX)
+//              (the kernel takes W2 and W1 as stored: their tiles are staged row-major and the MFMA fragments are read
+//               TRANSPOSED from LDS with ds_read_b64_tr_b16 - no per-step W^T copies of the trainable weights)
 //
 // so one kernel template serves both.  Structure: a workgroup owns 32 token rows (256 workgroups at 8192 tokens);
 //   * the 32 x h block of X is staged ONCE into LDS (XOR-swizzled 16-byte chunks) - it is the MFMA operand of the first
@@ -23,6 +25,7 @@
 // Rounding points are exactly those of the unfused path (mm_gemm_nt with MM_EPI_BIAS_RELU / MM_EPI_BIAS + residual /
 // MM_EPI_RELU_BWD / residual), and each output element's K-order is the same, so the results are bit-identical to it.
 #include "gemm_common.h"
+#include "mfma32.h"
 
 namespace mm {
 
@@ -57,20 +60,38 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
     const int m0 = blockIdx.x * AD_BM;
 
     // ---- weight staging: step s < S1 is Wa tile s, step S1 + c is Wb chunk c
+    // Forward: Wa = W1 [R][HID] and Wb = W2 [HID][R] are K-contiguous: tiles [n][k], fragments by ds_read_b128.
+    // Backward: the operands are W2^T and W1^T of the weights as stored, so a tile is staged as [k][n] (rows of the stored
+    // matrix) and fragments are read transposed; 32-byte segments are XOR-swizzled so that the 8 rows one half-wave
+    // touches per ds_read_b64_tr_b16 fall in different banks.
+    constexpr int T1SEG = HROW / 32;  // backward Wa tile: [64 k][R n], row = HROW bytes
+    auto tsw = [](int row, int nseg) { return nseg >= 8 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); };
     u32x4 wreg[S1 + S2][LMAX];
     auto w_issue = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         if constexpr (s < S1) {
 #pragma unroll
             for (int i = 0; i < L1N; ++i) {
-                const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-                wreg[s][i] = *reinterpret_cast<const u32x4*>(Wa + (size_t)row * HID + s * 64 + ch * 8);
+                const int c = tid + 256 * i;
+                if (MODE == 0) {
+                    const int row = c >> 3, ch = c & 7;
+                    wreg[s][i] = *reinterpret_cast<const u32x4*>(Wa + (size_t)row * HID + s * 64 + ch * 8);
+                } else {  // Wa = stored W2 [HID][R]: rows 64s .. 64s+63
+                    const int row = c / HCPR, ch = c % HCPR;
+                    wreg[s][i] = *reinterpret_cast<const u32x4*>(Wa + (size_t)(s * 64 + row) * R + ch * 8);
+                }
             }
         } else if constexpr (s < S1 + S2) {
 #pragma unroll
             for (int i = 0; i < L2N; ++i) {
-                const int c = tid + 256 * i, row = c / HCPR, ch = c % HCPR;
-                wreg[s][i] = *reinterpret_cast<const u32x4*>(Wb + (size_t)((s - S1) * CH2 + row) * R + ch * 8);
+                const int c = tid + 256 * i;
+                if (MODE == 0) {
+                    const int row = c / HCPR, ch = c % HCPR;
+                    wreg[s][i] = *reinterpret_cast<const u32x4*>(Wb + (size_t)((s - S1) * CH2 + row) * R + ch * 8);
+                } else {  // Wb = stored W1 [R][HID]: all R rows, columns CH2*c .. +CH2-1
+                    const int row = c >> 3, ch = c & 7;
+                    wreg[s][i] = *reinterpret_cast<const u32x4*>(Wb + (size_t)row * HID + (s - S1) * CH2 + ch * 8);
+                }
             }
         }
     };
@@ -81,16 +102,42 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
         } else if constexpr (s < S1) {
 #pragma unroll
             for (int i = 0; i < L1N; ++i) {
-                const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-                *reinterpret_cast<u32x4*>(buf + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = wreg[s][i];
+                const int c = tid + 256 * i;
+                if (MODE == 0) {
+                    const int row = c >> 3, ch = c & 7;
+                    *reinterpret_cast<u32x4*>(buf + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = wreg[s][i];
+                } else {
+                    const int row = c / HCPR, ch = c % HCPR;
+                    *reinterpret_cast<u32x4*>(buf + row * HROW + (((ch >> 1) ^ tsw(row, T1SEG)) << 5) + ((ch & 1) << 4)) = wreg[s][i];
+                }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < L2N; ++i) {
-                const int c = tid + 256 * i, row = c / HCPR, ch = c % HCPR;
-                *reinterpret_cast<u32x4*>(buf + row * HROW + ((ch ^ (row & HSW)) << 4)) = wreg[s][i];
+                const int c = tid + 256 * i;
+                if (MODE == 0) {
+                    const int row = c / HCPR, ch = c % HCPR;
+                    *reinterpret_cast<u32x4*>(buf + row * HROW + ((ch ^ (row & HSW)) << 4)) = wreg[s][i];
+                } else {  // [R k][CH2 n], rows of 128 bytes (4 segments)
+                    const int row = c >> 3, ch = c & 7;
+                    *reinterpret_cast<u32x4*>(buf + row * 128 + (((ch >> 1) ^ tsw(row, 4)) << 5) + ((ch & 1) << 4)) = wreg[s][i];
+                }
             }
         }
+    };
+    // transposed fragment of a [k][n] tile (row bytes rb, nseg 32-byte segments per row): lane (i = lane&15, g = lane>>4)
+    // gets tile[kb + 8g + j][n0 + i], j = 0..7 (lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3)
+    auto tr_frag16 = [&](const char* buf, int rb, int nseg, int kb, int n0) {
+        const int q = frow >> 2, pp = frow & 3;
+        const int r0 = kb + 8 * fq + q, r1 = r0 + 4;
+        const char* pa = buf + r0 * rb + (((n0 >> 4) ^ tsw(r0, nseg)) << 5) + 8 * pp;
+        const char* pb = buf + r1 * rb + (((n0 >> 4) ^ tsw(r1, nseg)) << 5) + 8 * pp;
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+        const s16x8 v = s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        frag f;
+        __builtin_memcpy(&f, &v, 16);
+        return f;
     };
 
     // ---- small operands first: a load that is issued late is waited for with vmcnt(0), i.e. it drains the whole weight
@@ -152,8 +199,12 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
                     FA[s][kk][mi] = *reinterpret_cast<const frag*>(Xs + (mi * 16 + frow) * XROW + (((s * 8 + kk * 4 + fq) ^ frow) << 4));
 #pragma unroll
                 for (int ni = 0; ni < NI1; ++ni) {
-                    const int n = nb1 + ni * 16 + frow;
-                    FB[s][kk][ni] = *reinterpret_cast<const frag*>(buf + n * 128 + (((kk * 4 + fq) ^ ((n >> 1) & 7)) << 4));
+                    if (MODE == 0) {
+                        const int n = nb1 + ni * 16 + frow;
+                        FB[s][kk][ni] = *reinterpret_cast<const frag*>(buf + n * 128 + (((kk * 4 + fq) ^ ((n >> 1) & 7)) << 4));
+                    } else {
+                        FB[s][kk][ni] = tr_frag16(buf, HROW, T1SEG, kk * 32, nb1 + ni * 16);
+                    }
                 }
             }
         }
@@ -166,8 +217,12 @@ __global__ __launch_bounds__(256) void bottleneck_k(u16* __restrict__ Y, u16* __
             for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
                 for (int ni = 0; ni < NI2; ++ni) {
-                    const int n = wave * (CH2 / 4) + ni * 16 + frow;  // row of the chunk
-                    FB2[c][ks][ni] = *reinterpret_cast<const frag*>(buf + n * HROW + (((ks * 4 + fq) ^ (n & HSW)) << 4));
+                    if (MODE == 0) {
+                        const int n = wave * (CH2 / 4) + ni * 16 + frow;  // row of the chunk
+                        FB2[c][ks][ni] = *reinterpret_cast<const frag*>(buf + n * HROW + (((ks * 4 + fq) ^ (n & HSW)) << 4));
+                    } else {
+                        FB2[c][ks][ni] = tr_frag16(buf, 128, 4, ks * 32, wave * (CH2 / 4) + ni * 16);
+                    }
                 }
         }
     };
@@ -315,14 +370,14 @@ extern "C" int mm_adapter_fwd(void* out, void* h1, const void* o, const void* w1
     });
 }
 
-extern "C" int mm_adapter_bwd_dx(void* dx, void* dpre, const void* dy, const void* w2t, const void* w1t, const void* h1, int rows,
+extern "C" int mm_adapter_bwd_dx(void* dx, void* dpre, const void* dy, const void* w2, const void* w1, const void* h1, int rows,
                                  int h, int r, int dtype, void* stream) {
-    MM_CHECK_ARG(dx && dpre && dy && w2t && w1t && h1, "mm_adapter_bwd_dx: null pointer");
+    MM_CHECK_ARG(dx && dpre && dy && w2 && w1 && h1, "mm_adapter_bwd_dx: null pointer");
     if (int rc = check_adapter("mm_adapter_bwd_dx", rows, h, r)) return rc;
-    MM_CHECK_ARG(aligned16(dx) && aligned16(dpre) && aligned16(dy) && aligned16(w2t) && aligned16(w1t) && aligned16(h1),
+    MM_CHECK_ARG(aligned16(dx) && aligned16(dpre) && aligned16(dy) && aligned16(w2) && aligned16(w1) && aligned16(h1),
                  "mm_adapter_bwd_dx: pointers must be 16-byte aligned");
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
-        return launch_bottleneck<T, 1>(dx, dpre, dy, w2t, nullptr, w1t, nullptr, h1, rows, h, r, (hipStream_t)stream);
+        return launch_bottleneck<T, 1>(dx, dpre, dy, w2, nullptr, w1, nullptr, h1, rows, h, r, (hipStream_t)stream);
     });
 }

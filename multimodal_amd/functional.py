@@ -153,7 +153,7 @@ class AdapterFn(torch.autograd.Function):
         g2 = _flat2d(g)
         do = None
         if ops.adapter_supported(w1.size(1), w1.size(0)):
-            do, dpre = ops.adapter_bwd_dx(g2, weight_t(w2), weight_t(w1), _flat2d(h1))
+            do, dpre = ops.adapter_bwd_dx(g2, w2.detach(), w1.detach(), _flat2d(h1))  # weights as stored: no W^T copies
             do = do.view(o.shape)
         else:
             # [M, r] data gradient through W2 and the ReLU in one kernel (the ReLU mask is the GEMM's epilogue)

@@ -343,15 +343,16 @@ def adapter_fwd(o, w1, b1, w2, b2):
     return out.view(o.shape), h1
 
 
-def adapter_bwd_dx(dy, w2t, w1t, h1):
-    """(dx, dpre) of the adapter: dpre = (dy W2) * (h1 > 0), dx = dy + dpre W1; w2t = W2^T [r, h], w1t = W1^T [h, r]."""
-    _need_cuda(dy, w2t, w1t, h1)
-    r, h = w2t.shape
+def adapter_bwd_dx(dy, w2, w1, h1):
+    """(dx, dpre) of the adapter: dpre = (dy W2) * (h1 > 0), dx = dy + dpre W1; W2 [h, r] and W1 [r, h] as stored."""
+    _need_cuda(dy, w2, w1, h1)
+    r, h = w1.shape
     dy2 = dy.contiguous().view(-1, h)
     dx = torch.empty_like(dy2)
     dpre = torch.empty(dy2.size(0), r, dtype=dy.dtype, device=dy.device)
-    check(get_lib().mm_adapter_bwd_dx(dx.data_ptr(), dpre.data_ptr(), dy2.data_ptr(), w2t.data_ptr(), w1t.data_ptr(),
-                                      h1.data_ptr(), dy2.size(0), h, r, dtype_code(dy.dtype), _stream()), "adapter_bwd_dx")
+    check(get_lib().mm_adapter_bwd_dx(dx.data_ptr(), dpre.data_ptr(), dy2.data_ptr(), w2.contiguous().data_ptr(),
+                                      w1.contiguous().data_ptr(), h1.data_ptr(), dy2.size(0), h, r, dtype_code(dy.dtype),
+                                      _stream()), "adapter_bwd_dx")
     return dx, dpre
 
 

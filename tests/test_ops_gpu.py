@@ -506,7 +506,7 @@ def test_adapter_fused_equals_gemm_chain(ops, cuda_device, dt, rows, h, r):
     out_ref = ops.gemm_nt(h1_ref, w2, b2, _lib.EPI_BIAS, residual=o)
     assert torch.equal(h1, h1_ref) and torch.equal(out, out_ref)
     w2t, w1t = ops.transpose2d(w2), ops.transpose2d(w1)
-    dx, dpre = ops.adapter_bwd_dx(g, w2t, w1t, h1)
+    dx, dpre = ops.adapter_bwd_dx(g, w2, w1, h1)   # takes the weights as stored, reads them transposed on chip
     dpre_ref = ops.gemm_nt(g, w2t, None, _lib.EPI_RELU_BWD, residual=h1)
     dx_ref = ops.gemm_nt(dpre_ref, w1t, residual=g)
     assert torch.equal(dpre, dpre_ref) and torch.equal(dx, dx_ref)

@@ -105,7 +105,7 @@ def bench_adapter():
     print("adapter_fwd    %8.1f us  (%.2f TB/s of o+out+h1)" % (t, (2 * T * H * 2 + T * r * 2) / t / 1e6))
     _, h1 = ops.adapter_fwd(o, w1, b1, w2, b2)
     w2t, w1t = ops.transpose2d(w2), ops.transpose2d(w1)
-    t = timeit(lambda: ops.adapter_bwd_dx(g, w2t, w1t, h1))
+    t = timeit(lambda: ops.adapter_bwd_dx(g, w2, w1, h1))
     print("adapter_bwd_dx %8.1f us" % t)
     t = timeit(lambda: (ops.gemm_tn(g, h1, with_colsum=True), ops.gemm_tn(h1, o, with_colsum=True)))
     print("adapter dW x2  %8.1f us" % t)
