@@ -83,10 +83,20 @@ template <typename T> __device__ __forceinline__ void unpack8(const u32x4& v, fl
         f[2 * i + 1] = to_f32<T>((u16)(v[i] >> 16));
     }
 }
+// two fp32 -> one dword of two 16-bit values (lo = a, hi = b), round-to-nearest-even: ONE v_cvt_pk_{bf16,f16}_f32
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b);
+template <> __device__ __forceinline__ uint32_t pack2<BF16>(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+template <> __device__ __forceinline__ uint32_t pack2<F16>(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
 template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
     u32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (uint32_t)from_f32<T>(f[2 * i]) | ((uint32_t)from_f32<T>(f[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) v[i] = pack2<T>(f[2 * i], f[2 * i + 1]);
     return v;
 }
 
@@ -106,6 +116,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float fast_tanh(float u) {
     const float e = __expf(2.0f * u);
     return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
+
+// tanh-GeLU (reference megatron/model/activations.py:62-70) in its sigmoid form: with u = 0.79788456 x (1 + 0.044715 x^2),
+// 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)) =: s, so gelu(x) = x s and, for bias_gelu_back (activations.py:75-86),
+// gelu'(x) = 0.5 x (1 - t^2)(0.79788456 + 0.1070322243 x^2) + 0.5 (1 + t) = s (1 + x (1.59576912 + 0.2140644486 x^2)(1 - s)).
+// 5 (forward) / 10 (derivative) plain VALU ops + one v_exp_f32 + one v_rcp_f32 per value; the constants fold -2 log2(e).
+// exp2 overflow (x << 0) gives s = 0, underflow s = 1: both limits are exact.
+__device__ __forceinline__ float gelu_sigmoid(float x, float x2) {
+    const float w = x * __builtin_fmaf(-0.1029432396f, x2, -2.302208198f);  // -2u log2(e)
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
+}
+__device__ __forceinline__ float gelu_tanh_fast(float x) { return x * gelu_sigmoid(x, x * x); }
+__device__ __forceinline__ float gelu_tanh_grad_fast(float x) {
+    const float x2 = x * x;
+    const float s = gelu_sigmoid(x, x2);
+    const float xc = x * __builtin_fmaf(0.2140644486f, x2, 1.59576912f);
+    return s * __builtin_fmaf(xc, 1.0f - s, 1.0f);
 }
 
 template <typename F> inline int dispatch_dtype(int dtype, F&& f) {

@@ -59,13 +59,8 @@ __global__ __launch_bounds__(256) void rotary_qk_k(u16* __restrict__ qkv, const 
 }
 
 // ------------------------------------------------------------------------------------ GeLU
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-    return x * 0.5f * (1.0f + fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x)));
-}
-__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
-    const float t = fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x));
-    return 0.5f * x * ((1.0f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.0f + t);
-}
+__device__ __forceinline__ float gelu_tanh_f(float x) { return gelu_tanh_fast(x); }
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) { return gelu_tanh_grad_fast(x); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);

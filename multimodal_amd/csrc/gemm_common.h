@@ -20,15 +20,10 @@ template <> struct Mfma<F16> {
     }
 };
 
-__device__ __forceinline__ float gelu_tanh_dev(float x) {
-    return x * 0.5f * (1.0f + fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x)));
-}
+__device__ __forceinline__ float gelu_tanh_dev(float x) { return gelu_tanh_fast(x); }
 __device__ __forceinline__ float gelu_erf_dev(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 // derivatives: the formulas of bias_gelu_back (reference megatron/model/activations.py:75-86) / of erf-GeLU
-__device__ __forceinline__ float gelu_tanh_grad_dev(float x) {
-    const float t = fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x));
-    return 0.5f * x * ((1.0f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.0f + t);
-}
+__device__ __forceinline__ float gelu_tanh_grad_dev(float x) { return gelu_tanh_grad_fast(x); }
 __device__ __forceinline__ float gelu_erf_grad_dev(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
@@ -62,48 +57,15 @@ template <typename T> __device__ __forceinline__ void load_bias4(float (&bv)[4],
     bv[2] = to_f32<T>((u16)(braw[1] & 0xffffu)); bv[3] = to_f32<T>((u16)(braw[1] >> 16));
 }
 
-// ---- coalesced epilogue of one wave's (MI*16) x 64 output tile, staged through a wave-private LDS region.
-// The MFMA accumulator layout gives a lane 4 consecutive columns (8 B) of 16 different rows: stored directly, one wave
-// instruction writes 16 separate 32-byte pieces and every 128-byte line of C is touched by 4 instructions - measured, that
-// store pattern costs as much as the whole K loop at K = 1024.  Instead:
-//   phase 1: epilogue math up to the first rounding, 8-byte ds_write into a [rows][128 B] image (16-byte chunk index
-//            XOR (row>>1)&7: conflict-free for these writes and for the reads below);
-//   phase 2: lane = (row l>>3, chunk l&7) reads 16 B back; one wave instruction now covers 8 full 128-byte rows of C.
-//            Residual add, the GeLU activation and the second output (aux) happen here, on 16-byte coalesced accesses.
-// Backward epilogues (MM_EPI_RELU_BWD / MM_EPI_GELU_*_BWD) take the saved forward tensor in the residual slot and apply the
-// activation's derivative to the rounded product, i.e. they are the data-gradient GEMM + the elementwise backward kernel.
-// Rounding order is the reference's eager order (product rounded, + bias rounded, activation, + residual rounded).  `wl` must not be shared with another wave; all
-// LDS traffic of the K loop must have completed for every wave (barrier) before the call.
-template <typename T, int EPI, bool RES, int MI>
-__device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char* wl, int m_base, int n_base, int M, int N, int ldc,
-                                                u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ bias,
+// phase 2 of epilogue_staged (see below): lane = (row l>>3, 16-byte chunk l&7) of each 8-row group of the staged image.
+// INTERIOR: the wave's whole (MI*16) x 64 tile lies inside C.
+template <typename T, int EPI, bool RES, int MI, bool INTERIOR>
+__device__ __forceinline__ void epilogue_phase2(const char* wl, int m_base, int n, int M, int N, int ldc, u16* __restrict__ C,
+                                                u16* __restrict__ aux, const u16* __restrict__ bias,
                                                 const u16* __restrict__ Rsd, int lane) {
     constexpr bool GELU = epi_is_gelu_fwd(EPI), GBWD = epi_is_gelu_bwd(EPI), RBWD = (EPI == MM_EPI_RELU_BWD);
-    static_assert(!(GBWD || RBWD) || RES, "backward epilogues take their second input in the residual slot");
-    const int frow = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n0 = n_base + ni * 16 + fq * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if ((EPI == MM_EPI_BIAS || EPI == MM_EPI_BIAS_RELU) && n0 < N) load_bias4<T>(bv, bias, n0);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int row = mi * 16 + frow;
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = acc[ni][mi][j];
-                if (EPI == MM_EPI_BIAS) o[j] += bv[j];
-                if (EPI == MM_EPI_BIAS_RELU) o[j] = fmaxf(rnd<T>(o[j] + bv[j]), 0.f);
-            }
-            const int phys = (ni * 2 + (fq >> 1)) ^ ((row >> 1) & 7);
-            *reinterpret_cast<u32x2*>(wl + row * 128 + phys * 16 + (fq & 1) * 8) =
-                u32x2{(uint32_t)from_f32<T>(o[0]) | ((uint32_t)from_f32<T>(o[1]) << 16),
-                      (uint32_t)from_f32<T>(o[2]) | ((uint32_t)from_f32<T>(o[3]) << 16)};
-        }
-    }
-    const int c = lane & 7, n = n_base + c * 8;
-    const bool full = n + 8 <= N, half = !full && n + 4 <= N;  // N % 4 == 0 is a precondition of the MFMA kernels
+    const int c = lane & 7;
+    const bool full = INTERIOR || n + 8 <= N, half = !full && n + 4 <= N;  // N % 4 == 0 is a precondition of the MFMA kernels
     float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (GELU || GBWD) {
         if (full) {
@@ -120,7 +82,7 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
         const int row = i * 8 + (lane >> 3);
         const int m = m_base + row;
         u32x4 v = *reinterpret_cast<const u32x4*>(wl + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        if (m >= M || !(full || half)) continue;
+        if (!INTERIOR && (m >= M || !(full || half))) continue;
         const size_t off = (size_t)m * ldc + n;
         if (GELU) {
             if (full) *reinterpret_cast<u32x4*>(aux + off) = v;
@@ -160,6 +122,53 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
         if (full) *reinterpret_cast<u32x4*>(C + off) = v;
         else *reinterpret_cast<u32x2*>(C + off) = u32x2{v[0], v[1]};
     }
+}
+
+// ---- coalesced epilogue of one wave's (MI*16) x 64 output tile, staged through a wave-private LDS region.
+// The MFMA accumulator layout gives a lane 4 consecutive columns (8 B) of 16 different rows: stored directly, one wave
+// instruction writes 16 separate 32-byte pieces and every 128-byte line of C is touched by 4 instructions - measured, that
+// store pattern costs as much as the whole K loop at K = 1024.  Instead:
+//   phase 1: epilogue math up to the first rounding, 8-byte ds_write into a [rows][128 B] image (16-byte chunk index
+//            XOR (row>>1)&7: conflict-free for these writes and for the reads below);
+//   phase 2: lane = (row l>>3, chunk l&7) reads 16 B back; one wave instruction now covers 8 full 128-byte rows of C.
+//            Residual add, the GeLU activation and the second output (aux) happen here, on 16-byte coalesced accesses.
+// Backward epilogues (MM_EPI_RELU_BWD / MM_EPI_GELU_*_BWD) take the saved forward tensor in the residual slot and apply the
+// activation's derivative to the rounded product, i.e. they are the data-gradient GEMM + the elementwise backward kernel.
+// Rounding order is the reference's eager order (product rounded, + bias rounded, activation, + residual rounded).  `wl` must not be shared with another wave; all
+// LDS traffic of the K loop must have completed for every wave (barrier) before the call.
+template <typename T, int EPI, bool RES, int MI>
+__device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char* wl, int m_base, int n_base, int M, int N, int ldc,
+                                                u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ bias,
+                                                const u16* __restrict__ Rsd, int lane) {
+    static_assert(!epi_is_bwd(EPI) || RES, "backward epilogues take their second input in the residual slot");
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n0 = n_base + ni * 16 + fq * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((EPI == MM_EPI_BIAS || EPI == MM_EPI_BIAS_RELU) && n0 < N) load_bias4<T>(bv, bias, n0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = mi * 16 + frow;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = acc[ni][mi][j];
+                if (EPI == MM_EPI_BIAS) o[j] += bv[j];
+                if (EPI == MM_EPI_BIAS_RELU) o[j] = fmaxf(rnd<T>(o[j] + bv[j]), 0.f);
+            }
+            const int phys = (ni * 2 + (fq >> 1)) ^ ((row >> 1) & 7);
+            *reinterpret_cast<u32x2*>(wl + row * 128 + phys * 16 + (fq & 1) * 8) =
+                u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+        }
+    }
+    const int c = lane & 7, n = n_base + c * 8;
+    // interior tiles (all of M = 8192-class problems) take a predicate-free copy of phase 2: no exec-mask branches, so the
+    // compiler batches the LDS reads / residual loads of several row groups ahead of the math
+    if (m_base + MI * 16 <= M && n_base + 64 <= N)
+        epilogue_phase2<T, EPI, RES, MI, true>(wl, m_base, n, M, N, ldc, C, aux, bias, Rsd, lane);
+    else
+        epilogue_phase2<T, EPI, RES, MI, false>(wl, m_base, n, M, N, ldc, C, aux, bias, Rsd, lane);
 }
 
 // gemm256.hip: returns MM_OK when it ran the problem, 1 when the shape is not one it takes (caller falls back), <0 on error.

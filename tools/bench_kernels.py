@@ -59,6 +59,7 @@ def bench_gemm():
     shapes = [("qkv  fwd", T, 3 * H, H, _lib.EPI_BIAS), ("h4h  gelu", T, 4 * H, H, _lib.EPI_BIAS_GELU_TANH),
               ("4hh  fwd", T, H, 4 * H, _lib.EPI_NONE), ("dense fwd", T, H, H, _lib.EPI_NONE),
               ("h4h  dx", T, H, 4 * H, _lib.EPI_NONE), ("4hh  dx", T, 4 * H, H, _lib.EPI_NONE),
+              ("4hh dx gelu'", T, 4 * H, H, _lib.EPI_GELU_TANH_BWD),
               ("qkv  dx", T, H, 3 * H, _lib.EPI_NONE), ("adapter dn", T, H // 8, H, _lib.EPI_BIAS_RELU),
               ("adapter up", T, H, H // 8, _lib.EPI_BIAS), ("lm head", T, 50432, H, _lib.EPI_NONE)]
     for name, M, N, K, epi in shapes:
@@ -66,11 +67,12 @@ def bench_gemm():
         w = [rnd(N, K, scale=0.02) for _ in range(3)]
         bias = rnd(N) if epi != _lib.EPI_NONE else None
         out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        res = rnd(M, N) if epi == _lib.EPI_GELU_TANH_BWD else None
         i = [0]
 
         def f():
             i[0] += 1
-            return ops.gemm_nt(a[i[0] % 3], w[i[0] % 3], bias, epi, out=out)
+            return ops.gemm_nt(a[i[0] % 3], w[i[0] % 3], bias, epi, residual=res, out=out)
         t = timeit(f, n=30, warm=5)
         print("gemm_nt %-10s M=%5d N=%5d K=%5d %8.1f us %7.1f TF/s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e6))
 
