@@ -133,11 +133,23 @@ enum {
     MM_EPI_BIAS_RELU = 4,
     MM_EPI_RELU_BWD = 5,
     MM_EPI_GELU_TANH_BWD = 6,
-    MM_EPI_GELU_ERF_BWD = 7
+    MM_EPI_GELU_ERF_BWD = 7,
+    MM_EPI_BIAS_ROTARY = 8 /* internal to mm_gemm_nt_qkv_rotary; mm_gemm_nt rejects it */
 };
 /* residual (optional, [M, N] with leading dimension ldc, may alias C): C = round(epilogue(...)) + residual. */
 int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual,
                int M, int N, int K, int lda, int ldb, int ldc, int epilogue, int dtype, void* stream);
+
+/* The QKV projection with the rotary embedding as its epilogue: C = rotary(A B^T + bias) - ColumnParallelLinear
+ * query_key_value followed by apply_rotary_pos_emb on the q and k slices (megatron/model/transformer.py:552-596,
+ * positional_embeddings.py:76-92) without the separate in-place pass over the activation.  C is the fused activation
+ * [M = s*b tokens, N = np*3*hn] (per head [q | k | v]); token row m sits at sequence position m / b + offset;
+ * cos/sin: [>= offset + s, d] tables in `dtype`.  The product + bias is rounded to `dtype` first and the rotation uses
+ * the eager reference's roundings, so C is bit-identical to mm_gemm_nt(MM_EPI_BIAS) + mm_rotary_qk_inplace.
+ * Fused shapes: hn == 64, d in {16, 32, 64}, N % 192 == 0, the MFMA path's alignment rules, M * b < 2^32;
+ * anything else returns MM_EUNSUPPORTED (run the two calls instead). */
+int mm_gemm_nt_qkv_rotary(void* C, const void* A, const void* B, const void* bias, const void* cos, const void* sin, int M,
+                          int N, int K, int lda, int ldb, int ldc, int b, int hn, int d, int offset, int dtype, void* stream);
 
 /* Weight gradient: C[N, Kp] = A[M, N]^T * B[M, Kp] (contraction over the token dimension M) - the dW = dY^T X half of
  * F.linear's backward (megatron/mpu/layers.py:557,745; adapter nn.Linear, megatron/model/adapter.py:18-24).
@@ -186,6 +198,15 @@ int mm_attn_fwd(void* ctx, float* lse, const void* qkv, const uint8_t* mask, int
 int mm_attn_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse,
                 const void* qkv, const uint8_t* mask, int mask_mode, int mask_batches, int s, int b,
                 int np, int hn, float softmax_scale, int dtype, void* stream);
+
+/* mm_attn_bwd with the backward of the rotary embedding fused into the dq / dk stores: dqkv is then the gradient wrt the
+ * PRE-rotary QKV activation, i.e. mm_attn_bwd followed by mm_rotary_qk_inplace(inverse = 1) (same roundings, bit-identical)
+ * without the extra pass (rotary backward of megatron/model/positional_embeddings.py:76-92 under autograd).
+ * cos/sin: [>= rot_offset + s, rot_d] tables in `dtype`; rot_d in {0 (off), 16, 32, 64, 128}, <= hn. */
+int mm_attn_bwd_rotary(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
+                       const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn,
+                       float softmax_scale, const void* cos, const void* sin, int rot_d, int rot_offset, int dtype,
+                       void* stream);
 
 /* ------------------------------------------------------------------ cross entropy (TP = 1)
  * Replaces vocab_parallel_cross_entropy(output.float(), labels) (megatron/mpu/cross_entropy.py:27-112 as called from

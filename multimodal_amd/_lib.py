@@ -42,6 +42,7 @@ PROTOTYPES = {
     "mm_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "mm_gptj_combine": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
     "mm_gemm_nt": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
+    "mm_gemm_nt_qkv_rotary": (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
     "mm_gemm_tn_splits": (c_int, [c_int, c_int, c_int]),
     "mm_adapter_supported": (c_int, [c_int, c_int]),
     "mm_adapter_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
@@ -51,6 +52,7 @@ PROTOTYPES = {
     "mm_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "mm_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mm_attn_bwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
+    "mm_attn_bwd_rotary": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_cross_entropy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_cross_entropy_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_debug_probe_tr_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

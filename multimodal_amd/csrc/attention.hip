@@ -223,12 +223,70 @@ __global__ __launch_bounds__(256) void attn_delta_k(float* __restrict__ delta, c
     }
 }
 
+
+// =====================================================================================  backward: gradient row store
+// One lane's share of a [HD] gradient row in the 32x32 accumulator layout: register 4*g4 + e of block d is head dim
+// 32*d + 8*g4 + 4*hh + e.  The row is scaled and rounded to T; with ROT > 0 the first ROT dims then go through the
+// TRANSPOSED rotary rotation (the backward of apply_rotary_pos_emb, megatron/model/positional_embeddings.py:76-92, with
+// the roundings of rotary_qk_k(inverse) in elementwise.hip): dim i < ROT/2 pairs with i + ROT/2, and since ROT/2 is a
+// multiple of 8 both live in the SAME lane - the rotation is register-local.  cosr / sinr: the row's table lines [ROT].
+template <typename T, int HD, int ROT>
+__device__ __forceinline__ void store_grad_row(u16* __restrict__ dst, const f32x16 (&acc)[HD / 32], float scale, int hh,
+                                               const u16* __restrict__ cosr, const u16* __restrict__ sinr) {
+    // No fma contraction here: for fp16 the compiler narrows these fp32 expressions to native half arithmetic and would then
+    // fuse rnd(a*b) +- rnd(c*d) into one half fma, skipping a rounding the eager reference performs.
+#pragma clang fp contract(off)
+    constexpr int NDB = HD / 32, HALF = ROT / 2;
+    float g[NDB][16];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[d][i] = rnd<T>(acc[d][i] * scale);
+    if constexpr (ROT > 0) {
+        static_for<0, HALF / 8>([&](auto gc) {  // 8-dim groups of the first half; this lane holds 4 dims of each
+            constexpr int cb = decltype(gc)::value * 8, pb = cb + HALF;
+            constexpr int d = cb / 32, g4 = (cb % 32) / 8, pd = pb / 32, pg = (pb % 32) / 8;
+            float c1[4], s1[4], c2[4], s2[4];
+            unpack4<T>(*reinterpret_cast<const u32x2*>(cosr + cb + 4 * hh), c1);
+            unpack4<T>(*reinterpret_cast<const u32x2*>(sinr + cb + 4 * hh), s1);
+            unpack4<T>(*reinterpret_cast<const u32x2*>(cosr + pb + 4 * hh), c2);
+            unpack4<T>(*reinterpret_cast<const u32x2*>(sinr + pb + 4 * hh), s2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g1 = g[d][4 * g4 + e], g2 = g[pd][4 * pg + e];
+                g[d][4 * g4 + e] = rnd<T>(g1 * c1[e]) + rnd<T>(g2 * s2[e]);
+                g[pd][4 * pg + e] = rnd<T>(g2 * c2[e]) - rnd<T>(g1 * s1[e]);
+            }
+        });
+    }
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            *reinterpret_cast<u32x2*>(dst + 32 * d + 8 * g4 + 4 * hh) =
+                u32x2{pack2<T>(g[d][4 * g4], g[d][4 * g4 + 1]), pack2<T>(g[d][4 * g4 + 2], g[d][4 * g4 + 3])};
+}
+// runtime rotary width -> the compile-time variants a head size supports (rot_d in {0, 16, 32, 64, 128}, <= HD)
+template <typename T, int HD>
+__device__ __forceinline__ void store_grad_row_rt(u16* __restrict__ dst, const f32x16 (&acc)[HD / 32], float scale, int hh,
+                                                  const u16* __restrict__ cos_t, const u16* __restrict__ sin_t, int rot_d, int pos) {
+    const u16* cr = cos_t + (size_t)pos * rot_d;
+    const u16* sr = sin_t + (size_t)pos * rot_d;
+    if (rot_d == 0) store_grad_row<T, HD, 0>(dst, acc, scale, hh, nullptr, nullptr);
+    else if (rot_d == 16) store_grad_row<T, HD, 16>(dst, acc, scale, hh, cr, sr);
+    else if (rot_d == 32) store_grad_row<T, HD, 32>(dst, acc, scale, hh, cr, sr);
+    else if (rot_d == 64) store_grad_row<T, HD, 64>(dst, acc, scale, hh, cr, sr);
+    else if constexpr (HD == 128) store_grad_row<T, HD, 128>(dst, acc, scale, hh, cr, sr);
+}
+
 // =====================================================================================  backward: dQ
 template <typename T, int HD, int MODE>
 __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                      const u16* __restrict__ qkv, const uint8_t* __restrict__ mask,
-                                                     int mask_batches, int s, int b, int np, float scale_log2e, float scale) {
+                                                     int mask_batches, int s, int b, int np, float scale_log2e, float scale,
+                                                     const u16* __restrict__ cos_t, const u16* __restrict__ sin_t, int rot_d,
+                                                     int rot_off) {
     typedef Tile<HD> TL;
     typedef typename M32<T>::frag frag;
     constexpr int NDS = HD / 16, NDB = HD / 32;
@@ -351,15 +409,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
     }
     if (qrow < s) {
         u16* orow = dqkv + (size_t)qrow * tok + ((size_t)bi * np + hi) * 3 * HD;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = 32 * d + 8 * g4 + 4 * hh;
-                const u16 a0 = from_f32<T>(dq[d][4 * g4] * scale), a1 = from_f32<T>(dq[d][4 * g4 + 1] * scale);
-                const u16 a2 = from_f32<T>(dq[d][4 * g4 + 2] * scale), a3 = from_f32<T>(dq[d][4 * g4 + 3] * scale);
-                *reinterpret_cast<u32x2*>(orow + d0) = u32x2{(uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16)};
-            }
+        store_grad_row_rt<T, HD>(orow, dq, scale, hh, cos_t, sin_t, rot_d, qrow + rot_off);
     }
 }
 
@@ -368,7 +418,9 @@ template <typename T, int HD, int MODE>
 __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       const u16* __restrict__ qkv, const uint8_t* __restrict__ mask,
-                                                      int mask_batches, int s, int b, int np, float scale_log2e, float scale) {
+                                                      int mask_batches, int s, int b, int np, float scale_log2e, float scale,
+                                                      const u16* __restrict__ cos_t, const u16* __restrict__ sin_t, int rot_d,
+                                                      int rot_off) {
     typedef Tile<HD> TL;
     typedef typename M32<T>::frag frag;
     constexpr int NDS = HD / 16, NDB = HD / 32;
@@ -536,19 +588,8 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
     }
     if (krow < s) {
         u16* krow_o = dqkv + (size_t)krow * tok + ((size_t)bi * np + hi) * 3 * HD + HD;
-        u16* vrow_o = krow_o + HD;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = 32 * d + 8 * g4 + 4 * hh;
-                u16 a0 = from_f32<T>(dk[d][4 * g4] * scale), a1 = from_f32<T>(dk[d][4 * g4 + 1] * scale);
-                u16 a2 = from_f32<T>(dk[d][4 * g4 + 2] * scale), a3 = from_f32<T>(dk[d][4 * g4 + 3] * scale);
-                *reinterpret_cast<u32x2*>(krow_o + d0) = u32x2{(uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16)};
-                a0 = from_f32<T>(dv[d][4 * g4]); a1 = from_f32<T>(dv[d][4 * g4 + 1]);
-                a2 = from_f32<T>(dv[d][4 * g4 + 2]); a3 = from_f32<T>(dv[d][4 * g4 + 3]);
-                *reinterpret_cast<u32x2*>(vrow_o + d0) = u32x2{(uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16)};
-            }
+        store_grad_row_rt<T, HD>(krow_o, dk, scale, hh, cos_t, sin_t, rot_d, krow + rot_off);
+        store_grad_row<T, HD, 0>(krow_o + HD, dv, 1.0f, hh, nullptr, nullptr);
     }
 }
 
@@ -571,7 +612,8 @@ static int launch_fwd(void* ctx, float* lse, const void* qkv, const uint8_t* mas
 
 template <typename T, int HD>
 static int launch_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
-                      const uint8_t* mask, int mode, int mb, int s, int b, int np, float scale, hipStream_t st) {
+                      const uint8_t* mask, int mode, int mb, int s, int b, int np, float scale, const u16* cs, const u16* sn,
+                      int rd, int ro, hipStream_t st) {
     const size_t nrows = (size_t)s * b * np;
     const size_t nthreads = nrows * (HD / 8);
     attn_delta_k<T, HD><<<(unsigned)((nthreads + 255) / 256), 256, 0, st>>>(delta, (const u16*)dctx, (const u16*)ctx, s, b, np);
@@ -579,13 +621,13 @@ static int launch_bwd(void* dqkv, float* delta, const void* dctx, const void* ct
     dim3 grid(b * np, (s + 127) / 128), block(256);  // head-fast, heavy blocks first (see launch_fwd)
     const float sl2 = scale * kLog2e;
     if (mode == 0) {
-        attn_bwd_dkv_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale);
+        attn_bwd_dkv_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale, cs, sn, rd, ro);
         MM_CHECK_LAUNCH();
-        attn_bwd_dq_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale);
+        attn_bwd_dq_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale, cs, sn, rd, ro);
     } else {
-        attn_bwd_dkv_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale);
+        attn_bwd_dkv_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale, cs, sn, rd, ro);
         MM_CHECK_LAUNCH();
-        attn_bwd_dq_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale);
+        attn_bwd_dq_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale, cs, sn, rd, ro);
     }
     MM_CHECK_LAUNCH();
     return MM_OK;
@@ -620,16 +662,32 @@ extern "C" int mm_attn_fwd(void* ctx, float* lse, const void* qkv, const uint8_t
     });
 }
 
-extern "C" int mm_attn_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
-                           const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn,
-                           float softmax_scale, int dtype, void* stream) {
+extern "C" int mm_attn_bwd_rotary(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
+                                  const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn,
+                                  float softmax_scale, const void* cos, const void* sin, int rot_d, int rot_offset, int dtype,
+                                  void* stream) {
     MM_CHECK_ARG(dqkv && delta && dctx && ctx && lse && qkv, "mm_attn_bwd: null pointer");
     if (int rc = check_common("mm_attn_bwd", mask_mode, mask, mask_batches, s, b, np, hn)) return rc;
     MM_CHECK_ARG(aligned16(qkv) && aligned16(ctx) && aligned16(dctx) && aligned16(dqkv), "mm_attn_bwd: tensors must be 16-byte aligned");
+    if (rot_d != 0) {
+        MM_CHECK_ARG(cos && sin && aligned16(cos) && aligned16(sin), "mm_attn_bwd_rotary: cos/sin tables missing or not 16-byte aligned");
+        MM_CHECK_ARG((rot_d == 16 || rot_d == 32 || rot_d == 64 || rot_d == 128) && rot_d <= hn && rot_offset >= 0,
+                     "mm_attn_bwd_rotary: rotary dims %d (offset %d) not supported for head size %d", rot_d, rot_offset, hn);
+    }
     hipStream_t st = (hipStream_t)stream;
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
-        if (hn == 64) return launch_bwd<T, 64>(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale, st);
-        return launch_bwd<T, 128>(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale, st);
+        if (hn == 64)
+            return launch_bwd<T, 64>(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale,
+                                     (const u16*)cos, (const u16*)sin, rot_d, rot_offset, st);
+        return launch_bwd<T, 128>(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale,
+                                  (const u16*)cos, (const u16*)sin, rot_d, rot_offset, st);
     });
+}
+
+extern "C" int mm_attn_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
+                           const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn,
+                           float softmax_scale, int dtype, void* stream) {
+    return mm_attn_bwd_rotary(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, hn, softmax_scale, nullptr,
+                              nullptr, 0, 0, dtype, stream);
 }

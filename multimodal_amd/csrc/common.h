@@ -83,6 +83,10 @@ template <typename T> __device__ __forceinline__ void unpack8(const u32x4& v, fl
         f[2 * i + 1] = to_f32<T>((u16)(v[i] >> 16));
     }
 }
+template <typename T> __device__ __forceinline__ void unpack4(const u32x2& v, float (&f)[4]) {
+    f[0] = to_f32<T>((u16)(v[0] & 0xffffu)); f[1] = to_f32<T>((u16)(v[0] >> 16));
+    f[2] = to_f32<T>((u16)(v[1] & 0xffffu)); f[3] = to_f32<T>((u16)(v[1] >> 16));
+}
 // two fp32 -> one dword of two 16-bit values (lo = a, hi = b), round-to-nearest-even: ONE v_cvt_pk_{bf16,f16}_f32
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;

@@ -20,6 +20,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void rotary_qk_k(u16* __restrict__ qkv, const u16* __restrict__ cos_t,
                                                    const u16* __restrict__ sin_t, int T_tokens, int b, int np, int hn,
                                                    int d, int offset, int inverse) {
+    // No fma contraction here: for fp16 the compiler narrows these fp32 expressions to native half arithmetic and would then
+    // fuse rnd(a*b) +- rnd(c*d) into one half fma, skipping a rounding the eager reference performs.
+#pragma clang fp contract(off)
     const int half = d >> 1;
     const int cpr = half >> 3;  // 8-element chunks per half
     const size_t total = (size_t)T_tokens * np * 2 * cpr;

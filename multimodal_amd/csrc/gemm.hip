@@ -42,7 +42,7 @@ template <typename T, int EPI, bool RES>
 __global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ A,
                                                      const u16* __restrict__ B, const u16* __restrict__ bias,
                                                      const u16* __restrict__ Rsd, int M, int N, int K, int lda, int ldb,
-                                                     int ldc, int tiles_m, int tiles_n) {
+                                                     int ldc, int tiles_m, int tiles_n, EpiExtra ex) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* _
     }
 
     // ---- epilogue (coalesced through a wave-private 8 KiB LDS region; the loop's last barrier retired all LDS traffic)
-    epilogue_staged<T, EPI, RES, 4>(acc, smem + wave * 8192, bm + wr * 64, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd, lane);
+    epilogue_staged<T, EPI, RES, 4>(acc, smem + wave * 8192, bm + wr * 64, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd, lane, ex);
 }
 
 
@@ -154,18 +154,19 @@ __global__ __launch_bounds__(256) void gemm_nt_generic_k(u16* __restrict__ C, u1
 
 template <typename T, int EPI>
 static int launch_gemm(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N,
-                       int K, int lda, int ldb, int ldc, hipStream_t st) {
+                       int K, int lda, int ldb, int ldc, hipStream_t st, const EpiExtra& ex = EpiExtra{}) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(256);
-    if constexpr (epi_is_bwd(EPI)) {  // the residual slot carries the saved forward tensor: always present
-        gemm_nt_128_k<T, EPI, true><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
-                                                            (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n);
-    } else if (residual)
-        gemm_nt_128_k<T, EPI, true><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
-                                                            (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n);
-    else
+    // backward epilogues: the residual slot carries the saved forward tensor (always present); the rotary epilogue: the
+    // aux / residual slots carry the cos / sin tables and there is no residual add
+    if (EPI != MM_EPI_BIAS_ROTARY && (epi_is_bwd(EPI) || residual)) {
+        if constexpr (EPI != MM_EPI_BIAS_ROTARY)
+            gemm_nt_128_k<T, EPI, true><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
+                                                                (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, ex);
+    } else if constexpr (!epi_is_bwd(EPI)) {
         gemm_nt_128_k<T, EPI, false><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
-                                                             nullptr, M, N, K, lda, ldb, ldc, tiles_m, tiles_n);
+                                                             (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, ex);
+    }
     MM_CHECK_LAUNCH();
     return MM_OK;
 }
@@ -215,5 +216,29 @@ extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, cons
             case MM_EPI_GELU_TANH_BWD: return launch_gemm<T, MM_EPI_GELU_TANH_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
             default: return launch_gemm<T, MM_EPI_GELU_ERF_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
         }
+    });
+}
+
+extern "C" int mm_gemm_nt_qkv_rotary(void* C, const void* A, const void* B, const void* bias, const void* cos, const void* sin,
+                                     int M, int N, int K, int lda, int ldb, int ldc, int b, int hn, int d, int offset, int dtype,
+                                     void* stream) {
+    MM_CHECK_ARG(C && A && B && bias && cos && sin, "mm_gemm_nt_qkv_rotary: null pointer");
+    MM_CHECK_ARG(M > 0 && N > 0 && K > 0 && b > 0, "mm_gemm_nt_qkv_rotary: M=%d N=%d K=%d b=%d must be positive", M, N, K, b);
+    MM_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "mm_gemm_nt_qkv_rotary: leading dimensions too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    MM_CHECK_ARG(offset >= 0 && d > 0 && d <= hn, "mm_gemm_nt_qkv_rotary: rotary dims %d / offset %d out of range (hn=%d)", d, offset, hn);
+    const bool al = ((((uintptr_t)C) | ((uintptr_t)bias)) & 7) == 0 && aligned16(A) && aligned16(B) && aligned16(cos) && aligned16(sin);
+    const bool ok = hn == 64 && (d == 16 || d == 32 || d == 64) && N % 192 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+                    ldc % 4 == 0 && al && (uint64_t)M * (uint64_t)b < (1ull << 32);
+    if (!ok) {
+        mm::set_error("mm_gemm_nt_qkv_rotary: not a fused shape (hn=%d d=%d N=%d K=%d b=%d): use mm_gemm_nt + mm_rotary_qk_inplace", hn, d, N, K, b);
+        return MM_EUNSUPPORTED;
+    }
+    const EpiExtra ex{b > 1 ? (uint32_t)((1ull << 32) / (uint64_t)b) + 1u : 0u, b, d, offset};
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = gemm256_try(C, const_cast<void*>(cos), A, B, bias, sin, M, N, K, lda, ldb, ldc, MM_EPI_BIAS_ROTARY, dtype, st, ex);
+    if (rc <= 0) return rc;
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        return launch_gemm<T, MM_EPI_BIAS_ROTARY>(C, const_cast<void*>(cos), A, B, bias, sin, M, N, K, lda, ldb, ldc, st, ex);
     });
 }

@@ -81,7 +81,7 @@ template <typename T, int EPI, bool RES>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256_k(u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ A,
                                                         const u16* __restrict__ B, const u16* __restrict__ bias,
                                                         const u16* __restrict__ Rsd, int M, int N, int K, int lda, int ldb,
-                                                        int ldc, int tiles_m, int tiles_n, int group_m) {
+                                                        int ldc, int tiles_m, int tiles_n, int group_m, EpiExtra ex) {
     __shared__ __attribute__((aligned(16))) char smem[G::LDS];  // the ONLY LDS object of the kernel
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int tm, tn;
@@ -170,39 +170,43 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256_k(u16* __restrict__ C, u16
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue (coalesced through a wave-private 16 KiB LDS region)
-    epilogue_staged<T, EPI, RES, 8>(acc, smem + wave * 16384, bm + wr * 128, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd, lane);
+    epilogue_staged<T, EPI, RES, 8>(acc, smem + wave * 16384, bm + wr * 128, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd, lane, ex);
 }
 
 template <typename T, int EPI>
 static int launch256(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
-                     int lda, int ldb, int ldc, hipStream_t st) {
+                     int lda, int ldb, int ldc, hipStream_t st, const EpiExtra& ex) {
     const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
     const int nwg = tiles_m * tiles_n;
     int group_m = (nwg / 8) / tiles_n;  // one XCD's run of tiles spans whole tile-rows when it can
     group_m = group_m < 1 ? 1 : (group_m > 8 ? 8 : group_m);
     dim3 grid(nwg), block(512);
-    if (epi_is_bwd(EPI) || residual)
-        gemm_nt_256_k<T, EPI, true><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
-                                                                     (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, group_m);
-    else if constexpr (!epi_is_bwd(EPI))
+    // (the rotary epilogue carries its tables in the aux / residual slots: never a residual add)
+    if (EPI != MM_EPI_BIAS_ROTARY && (epi_is_bwd(EPI) || residual)) {
+        if constexpr (EPI != MM_EPI_BIAS_ROTARY)
+            gemm_nt_256_k<T, EPI, true><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
+                                                                (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, group_m, ex);
+    } else if constexpr (!epi_is_bwd(EPI)) {
         gemm_nt_256_k<T, EPI, false><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
-                                                                      nullptr, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, group_m);
+                                                             (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, group_m, ex);
+    }
     MM_CHECK_LAUNCH();
     return MM_OK;
 }
 
 template <typename T>
 static int launch256_epi(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N,
-                         int K, int lda, int ldb, int ldc, int epilogue, hipStream_t st) {
+                         int K, int lda, int ldb, int ldc, int epilogue, hipStream_t st, const EpiExtra& ex) {
     switch (epilogue) {
-        case MM_EPI_NONE: return launch256<T, MM_EPI_NONE>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
-        case MM_EPI_BIAS: return launch256<T, MM_EPI_BIAS>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
-        case MM_EPI_BIAS_GELU_TANH: return launch256<T, MM_EPI_BIAS_GELU_TANH>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
-        case MM_EPI_BIAS_GELU_ERF: return launch256<T, MM_EPI_BIAS_GELU_ERF>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
-        case MM_EPI_BIAS_RELU: return launch256<T, MM_EPI_BIAS_RELU>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
-        case MM_EPI_RELU_BWD: return launch256<T, MM_EPI_RELU_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
-        case MM_EPI_GELU_TANH_BWD: return launch256<T, MM_EPI_GELU_TANH_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
-        default: return launch256<T, MM_EPI_GELU_ERF_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st);
+        case MM_EPI_BIAS_ROTARY: return launch256<T, MM_EPI_BIAS_ROTARY>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_NONE: return launch256<T, MM_EPI_NONE>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_BIAS: return launch256<T, MM_EPI_BIAS>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_BIAS_GELU_TANH: return launch256<T, MM_EPI_BIAS_GELU_TANH>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_BIAS_GELU_ERF: return launch256<T, MM_EPI_BIAS_GELU_ERF>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_BIAS_RELU: return launch256<T, MM_EPI_BIAS_RELU>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_RELU_BWD: return launch256<T, MM_EPI_RELU_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_GELU_TANH_BWD: return launch256<T, MM_EPI_GELU_TANH_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        default: return launch256<T, MM_EPI_GELU_ERF_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
     }
 }
 
@@ -211,7 +215,7 @@ static int launch256_epi(void* C, void* aux, const void* A, const void* B, const
 // M = 8192 (TFLOP/s, this kernel vs gemm.hip): N=4096 K=1024 1058 vs 879, N=50432 K=1024 999 vs 810, N=3072 (1.5 rounds) 791 vs 807,
 // N=1024 (half a round) 690 vs 990.
 int gemm256_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
-                int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st) {
+                int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st, const EpiExtra& ex) {
     int force = 0;
     if (const char* e = getenv("MM_GEMM256")) force = atoi(e);  // developer switch: 1 = always (when legal), -1 = never
     if (force < 0 || M < 256 || N < 256 || K < 128) return 1;
@@ -221,7 +225,7 @@ int gemm256_try(void* C, void* aux, const void* A, const void* B, const void* bi
     if (force == 0 && !(tiles % 256 == 0 || tiles >= 1024)) return 1;
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
-        return launch256_epi<T>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, st);
+        return launch256_epi<T>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, st, ex);
     });
 }
 

@@ -27,6 +27,12 @@ __device__ __forceinline__ float gelu_tanh_grad_dev(float x) { return gelu_tanh_
 __device__ __forceinline__ float gelu_erf_grad_dev(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
+// MM_EPI_BIAS_ROTARY (mm_gemm_nt_qkv_rotary only): bias, then the rotary embedding on the q and k slices of the fused
+// QKV activation.  The kernels' `aux` / `residual` pointer slots carry the cos / sin tables; EpiExtra the integers.
+struct EpiExtra {
+    uint32_t magic;  // floor(2^32 / b) + 1: token row m -> sequence position m / b by one v_mul_hi_u32 (b > 1, M * b < 2^32)
+    int b, d, offset;
+};
 // which epilogues read `bias` / use the `residual` slot as a second INPUT (not an addend)
 constexpr bool epi_is_gelu_fwd(int e) { return e == MM_EPI_BIAS_GELU_TANH || e == MM_EPI_BIAS_GELU_ERF; }
 constexpr bool epi_is_gelu_bwd(int e) { return e == MM_EPI_GELU_TANH_BWD || e == MM_EPI_GELU_ERF_BWD; }
@@ -46,10 +52,6 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
     tn = (bid % group_sz) / gm;
 }
 
-template <typename T> __device__ __forceinline__ void unpack4(const u32x2& v, float (&f)[4]) {
-    f[0] = to_f32<T>((u16)(v[0] & 0xffffu)); f[1] = to_f32<T>((u16)(v[0] >> 16));
-    f[2] = to_f32<T>((u16)(v[1] & 0xffffu)); f[3] = to_f32<T>((u16)(v[1] >> 16));
-}
 // bias values of 4 consecutive columns
 template <typename T> __device__ __forceinline__ void load_bias4(float (&bv)[4], const u16* __restrict__ bias, int n0) {
     const u32x2 braw = *reinterpret_cast<const u32x2*>(bias + n0);
@@ -124,6 +126,48 @@ __device__ __forceinline__ void epilogue_phase2(const char* wl, int m_base, int 
     }
 }
 
+// Rotary embedding on a wave's staged (MI*16) x 64 tile, between the two phases of epilogue_staged.  Head size 64 and
+// 64-column wave tiles make every tile exactly one q, k or v slice of one head (fused layout [np][q | k | v],
+// megatron/model/transformer.py:555-564); v tiles skip this (wave-uniform).  Work item = (row, 16-byte piece pc of the
+// first half) together with its partner piece in the second half, one item per lane and pass, so every lane does useful
+// work: with d = 16 a 64-row tile is ONE pass.  Arithmetic and rounding are those of rotary_qk_k (elementwise.hip), i.e. of
+// apply_rotary_pos_emb (megatron/model/positional_embeddings.py:76-92) on the rounded GEMM output.
+template <typename T, int MI>
+__device__ __forceinline__ void epilogue_rotary_pass(char* wl, int m_base, int n_base, int M, const u16* __restrict__ cos_t,
+                                                     const u16* __restrict__ sin_t, const EpiExtra& ex, int lane) {
+    // No fma contraction here: for fp16 the compiler narrows these fp32 expressions to native half arithmetic and would then
+    // fuse rnd(a*b) +- rnd(c*d) into one half fma, skipping a rounding the eager reference performs.
+#pragma clang fp contract(off)
+    if ((n_base >> 6) % 3 == 2) return;  // a v slice
+    const int half = ex.d >> 1;
+    const int lp = (half == 8) ? 0 : (half == 16 ? 1 : 2);  // log2(pieces per half): d in {16, 32, 64}
+    const int items = (MI * 16) << lp;
+    for (int it = lane; it < items; it += 64) {
+        const int row = it >> lp, pc = it & ((1 << lp) - 1);
+        const int m = min(m_base + row, M - 1);
+        const int pos = (int)(ex.b == 1 ? (uint32_t)m : __umulhi((uint32_t)m, ex.magic)) + ex.offset;
+        const int sw = (row >> 1) & 7;
+        u32x4* p1 = reinterpret_cast<u32x4*>(wl + row * 128 + ((pc ^ sw) << 4));
+        u32x4* p2 = reinterpret_cast<u32x4*>(wl + row * 128 + (((pc + (1 << lp)) ^ sw) << 4));
+        const u16* cp = cos_t + (size_t)pos * ex.d + pc * 8;
+        const u16* sp = sin_t + (size_t)pos * ex.d + pc * 8;
+        float x1[8], x2[8], c1[8], c2[8], s1[8], s2[8], o1[8], o2[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(cp), c1);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(cp + half), c2);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(sp), s1);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(sp + half), s2);
+        unpack8<T>(*p1, x1);
+        unpack8<T>(*p2, x2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o1[j] = rnd<T>(x1[j] * c1[j]) + rnd<T>(-x2[j] * s1[j]);
+            o2[j] = rnd<T>(x2[j] * c2[j]) + rnd<T>(x1[j] * s2[j]);
+        }
+        *p1 = pack8<T>(o1);
+        *p2 = pack8<T>(o2);
+    }
+}
+
 // ---- coalesced epilogue of one wave's (MI*16) x 64 output tile, staged through a wave-private LDS region.
 // The MFMA accumulator layout gives a lane 4 consecutive columns (8 B) of 16 different rows: stored directly, one wave
 // instruction writes 16 separate 32-byte pieces and every 128-byte line of C is touched by 4 instructions - measured, that
@@ -139,14 +183,14 @@ __device__ __forceinline__ void epilogue_phase2(const char* wl, int m_base, int 
 template <typename T, int EPI, bool RES, int MI>
 __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char* wl, int m_base, int n_base, int M, int N, int ldc,
                                                 u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ bias,
-                                                const u16* __restrict__ Rsd, int lane) {
+                                                const u16* __restrict__ Rsd, int lane, const EpiExtra& ex = EpiExtra{}) {
     static_assert(!epi_is_bwd(EPI) || RES, "backward epilogues take their second input in the residual slot");
     const int frow = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int n0 = n_base + ni * 16 + fq * 4;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if ((EPI == MM_EPI_BIAS || EPI == MM_EPI_BIAS_RELU) && n0 < N) load_bias4<T>(bv, bias, n0);
+        if ((EPI == MM_EPI_BIAS || EPI == MM_EPI_BIAS_RELU || EPI == MM_EPI_BIAS_ROTARY) && n0 < N) load_bias4<T>(bv, bias, n0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int row = mi * 16 + frow;
@@ -154,7 +198,7 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 o[j] = acc[ni][mi][j];
-                if (EPI == MM_EPI_BIAS) o[j] += bv[j];
+                if (EPI == MM_EPI_BIAS || EPI == MM_EPI_BIAS_ROTARY) o[j] += bv[j];
                 if (EPI == MM_EPI_BIAS_RELU) o[j] = fmaxf(rnd<T>(o[j] + bv[j]), 0.f);
             }
             const int phys = (ni * 2 + (fq >> 1)) ^ ((row >> 1) & 7);
@@ -162,6 +206,7 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
                 u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
         }
     }
+    if constexpr (EPI == MM_EPI_BIAS_ROTARY) epilogue_rotary_pass<T, MI>(wl, m_base, n_base, M, aux, Rsd, ex, lane);
     const int c = lane & 7, n = n_base + c * 8;
     // interior tiles (all of M = 8192-class problems) take a predicate-free copy of phase 2: no exec-mask branches, so the
     // compiler batches the LDS reads / residual loads of several row groups ahead of the math
@@ -173,6 +218,6 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
 
 // gemm256.hip: returns MM_OK when it ran the problem, 1 when the shape is not one it takes (caller falls back), <0 on error.
 int gemm256_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
-                int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st);
+                int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st, const EpiExtra& ex = EpiExtra{});
 
 }  // namespace mm

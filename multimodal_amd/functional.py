@@ -264,14 +264,57 @@ class AttentionCoreFn(torch.autograd.Function):
     def backward(ctx, dctx):
         qkv, out, lse, cos, sin, mask = ctx.saved_tensors
         s, b, np_, hn, d, scale = ctx.dims
-        dqkv = ops.attn_bwd(dctx, out, lse, qkv, s, b, np_, hn, scale, mask)
-        if d > 0:
-            ops.rotary_qk_inplace(dqkv, cos, sin, s, b, np_, hn, d, inverse=True)
+        # the rotary backward rides in the dq / dk stores of the attention backward kernels
+        dqkv = ops.attn_bwd(dctx, out, lse, qkv, s, b, np_, hn, scale, mask, rotary=(cos, sin, d, 0) if d > 0 else None)
         return dqkv.view(s, b, np_ * 3 * hn), None, None, None, None, None, None, None
 
 
 def attention_core(mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale):
     return AttentionCoreFn.apply(mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale)
+
+
+def bias_needed(ctx):
+    return ctx.has_bias and ctx.needs_input_grad[2]
+
+
+class QkvAttentionFn(torch.autograd.Function):
+    """ctx = attention(rotary(x Wqkv^T + b)) - query_key_value + rotary + the attention core of ParallelSelfAttention
+    (megatron/model/transformer.py:552-630) as one autograd node, so that the rotary embedding is the QKV GEMM's epilogue
+    and its backward sits in the attention backward's stores: no pass over the [s, b, 3h] activation in either direction.
+    Falls back to GEMM + in-place rotary for shapes the fused epilogue does not take (head size 128)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale):
+        s, b = x.size(0), x.size(1)
+        d = rotary_ndims
+        if d > 0 and bias is not None and ops.qkv_rotary_supported(hn, d, weight.size(0), weight.size(1), s * b, b):
+            mixed = ops.gemm_nt_qkv_rotary(x, weight, bias, cos, sin, b, hn, d)
+        else:
+            mixed = ops.gemm_nt(x, weight, bias, _lib.EPI_BIAS if bias is not None else _lib.EPI_NONE)
+            if d > 0:
+                ops.rotary_qk_inplace(mixed.view(s, b, np_, 3 * hn), cos, sin, s, b, np_, hn, d)
+        qkv = mixed.view(s, b, np_, 3 * hn)
+        out, lse = ops.attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask)
+        ctx.save_for_backward(x, weight, qkv, out, lse, cos, sin, mask)
+        ctx.dims = (s, b, np_, hn, d, softmax_scale)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        x, weight, qkv, out, lse, cos, sin, mask = ctx.saved_tensors
+        s, b, np_, hn, d, scale = ctx.dims
+        dmixed = ops.attn_bwd(dctx, out, lse, qkv, s, b, np_, hn, scale, mask, rotary=(cos, sin, d, 0) if d > 0 else None)
+        d2 = dmixed.view(s * b, np_ * 3 * hn)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(d2, weight_t(weight)).view(x.shape)
+        dw, db = _wgrad_bias(d2, _flat2d(x), ctx.needs_input_grad[1], bias_needed(ctx))
+        return dx, dw, db, None, None, None, None, None, None, None
+
+
+def qkv_attention(x, weight, bias, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale):
+    return QkvAttentionFn.apply(x, weight, bias, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale)
 
 
 class BiasDropoutAddFn(torch.autograd.Function):

@@ -124,16 +124,20 @@ class ParallelSelfAttention(nn.Module):
             raise NotImplementedError("kv-cache inference is outside this path's scope (training hot path only)")
         s, b = hidden_states.size(0), hidden_states.size(1)
         np_, hn = self.num_attention_heads_per_partition, self.hidden_size_per_attention_head
-        mixed, _ = self.query_key_value(hidden_states)  # [s, b, np*3*hn], per-head interleaved (q, k, v)
         cos = sin = None
         d = 0
         if exists(self.rotary_emb):
             d = self.rotary_ndims if exists(self.rotary_ndims) else hn
-            cos, sin = self.rotary_emb.tables(mixed, s)
+            cos, sin = self.rotary_emb.tables(hidden_states, s)
         # the fused causal kernel ignores the mask tensor (fused_softmax.py:173-179); otherwise a mask that IS the
         # plain causal one takes the same fast path (identical result: exp(-10000 - max) == 0 in fp32)
         mask = None if (self.upper_triang_fusion or _is_plain_causal(attention_mask)) else attention_mask
-        context = Fn.attention_core(mixed, cos, sin, mask, np_, hn, d, 1.0 / self.norm_factor)  # [s, b, np*hn]
+        # query_key_value (ColumnParallelLinear, gather_output=False: mpu/layers.py:549-564) + rotary + attention core as one
+        # node: the fused QKV activation [s, b, np*3*hn] (per-head interleaved q, k, v) is produced already rotated
+        qkv_lin = self.query_key_value
+        x = mpu.copy_to_model_parallel_region(hidden_states)
+        context = Fn.qkv_attention(x, qkv_lin.weight, qkv_lin.bias, cos, sin, mask, np_, hn, d,
+                                   1.0 / self.norm_factor)  # [s, b, np*hn]
         return self.dense(context)
 
 

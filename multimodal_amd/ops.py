@@ -279,6 +279,31 @@ def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, wa
     return (c, None) if want_aux else c
 
 
+def qkv_rotary_supported(hn, d, n_out, k_in, rows, b):
+    """Shapes the fused QKV-projection + rotary epilogue takes (mm_gemm_nt_qkv_rotary)."""
+    return hn == 64 and d in (16, 32, 64) and n_out % 192 == 0 and k_in % 64 == 0 and rows * b < (1 << 32)
+
+
+def gemm_nt_qkv_rotary(x, w, bias, cos, sin, b, hn, d, offset=0):
+    """rotary(x W^T + bias) on the q / k slices of the fused QKV activation, in the GEMM's epilogue.
+    x: [..., K] with rows ordered [s, b]; cos/sin: [>= offset + s, d] tables in x's dtype.  Bit-identical to
+    gemm_nt(x, w, bias) followed by rotary_qk_inplace."""
+    _need_cuda(x, w, bias, cos, sin)
+    K = x.size(-1)
+    x2 = x.contiguous().view(-1, K)
+    w = w.contiguous()
+    M, N = x2.size(0), w.size(0)
+    if w.size(1) != K or bias.numel() != N:
+        raise RuntimeError("gemm_nt_qkv_rotary: shape mismatch")
+    if cos.dtype != x.dtype or sin.dtype != x.dtype or cos.size(-1) != d or cos.numel() < (offset + M // b) * d:
+        raise RuntimeError("gemm_nt_qkv_rotary: cos/sin tables must be [>=offset+s, d] in the activation dtype")
+    c = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    check(get_lib().mm_gemm_nt_qkv_rotary(c.data_ptr(), x2.data_ptr(), w.data_ptr(), bias.contiguous().data_ptr(),
+                                          cos.contiguous().data_ptr(), sin.contiguous().data_ptr(), M, N, K, K, K, N, b, hn, d,
+                                          offset, dtype_code(x.dtype), _stream()), "gemm_nt_qkv_rotary")
+    return c.view(*x.shape[:-1], N)
+
+
 def gemm_tn(a, b, with_colsum=False):
     """C[N, Kp] = A[M, N]^T @ B[M, Kp] (weight gradient); ``with_colsum`` also returns sum_m A[m, :] (the bias gradient of
     the same backward) computed from the tiles the GEMM stages anyway.  Uses the transposed-read split-K kernel when the
@@ -371,15 +396,25 @@ def attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask=None):
     return ctx, lse
 
 
-def attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, softmax_scale, mask=None):
+def attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, softmax_scale, mask=None, rotary=None):
+    """Gradient wrt qkv [s, b, np, 3*hn].  rotary = (cos, sin, d, offset): also apply the rotary embedding's backward to
+    the q / k gradients inside the kernels' stores (the result is then the gradient wrt the PRE-rotary activation)."""
     _need_cuda(dctx, ctx, lse, qkv, mask)
     dctx = dctx.contiguous()
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(b, np_, s, dtype=torch.float32, device=qkv.device)
     m, mode, mb = _mask_args(mask, s, b)
-    check(get_lib().mm_attn_bwd(dqkv.data_ptr(), delta.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
-                                qkv.data_ptr(), _ptr(m), mode, mb, s, b, np_, hn, float(softmax_scale),
-                                dtype_code(qkv.dtype), _stream()), "attn_bwd")
+    cos = sin = None
+    d = off = 0
+    if rotary is not None:
+        cos, sin, d, off = rotary
+        _need_cuda(cos, sin)
+        if cos.dtype != qkv.dtype or sin.dtype != qkv.dtype or cos.size(-1) != d or cos.numel() < (off + s) * d:
+            raise RuntimeError("attn_bwd: cos/sin tables must be [>=offset+s, d] in the activation dtype")
+        cos, sin = cos.contiguous(), sin.contiguous()
+    check(get_lib().mm_attn_bwd_rotary(dqkv.data_ptr(), delta.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                       qkv.data_ptr(), _ptr(m), mode, mb, s, b, np_, hn, float(softmax_scale), _ptr(cos),
+                                       _ptr(sin), d, off, dtype_code(qkv.dtype), _stream()), "attn_bwd")
     return dqkv
 
 

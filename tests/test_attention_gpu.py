@@ -113,3 +113,31 @@ def test_attention_410m_shape_properties(cuda_device):
     tot = dv.sum(dim=0)  # [b, np, hn]
     assert (tot / s - 1.0).abs().max() <= 2e-2
     assert torch.isfinite(dqkv.float()).all()
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("s,b,np_,hn,d,offset,mode", [(200, 2, 2, 64, 16, 0, "causal"), (128, 1, 3, 64, 64, 3, "causal"),
+                                                      (96, 2, 2, 64, 32, 0, "general"), (160, 2, 2, 128, 128, 0, "causal"),
+                                                      (130, 1, 2, 128, 32, 1, "causal"), (64, 2, 1, 128, 64, 0, "general")])
+def test_attention_bwd_fused_rotary_equals_two_passes(cuda_device, dt, s, b, np_, hn, d, offset, mode):
+    """mm_attn_bwd_rotary (rotary backward inside the dq / dk stores) is bit-identical to mm_attn_bwd followed by
+    mm_rotary_qk_inplace(inverse)."""
+    from multimodal_amd import ops
+    dtype = DT[dt]
+    torch.manual_seed(s + d)
+    qkv = torch.randn(s, b, np_, 3 * hn).to(dtype).to(cuda_device)
+    dctx = torch.randn(s, b, np_ * hn).to(dtype).to(cuda_device)
+    mask = (torch.rand(b, 1, s, s) < 0.3).to(cuda_device) if mode == "general" else None
+    pos = torch.arange(offset + s, dtype=torch.float32)
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    emb = torch.cat((pos[:, None] * inv[None, :],) * 2, dim=-1)
+    cos, sin = emb.cos().to(dtype).to(cuda_device), emb.sin().to(dtype).to(cuda_device)
+    scale = 1.0 / math.sqrt(hn)
+    ctx, lse = ops.attn_fwd(qkv, s, b, np_, hn, scale, mask)
+    fused = ops.attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, scale, mask, rotary=(cos, sin, d, offset))
+    two = ops.attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, scale, mask)
+    plain = two.clone()
+    ops.rotary_qk_inplace(two, cos, sin, s, b, np_, hn, d, offset, inverse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.view(torch.int16), two.view(torch.int16))
+    assert not torch.equal(fused[1:, ..., :d], plain[1:, ..., :d])

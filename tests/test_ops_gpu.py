@@ -540,3 +540,49 @@ def test_gemm_tn_pair_equals_two_calls(ops, cuda_device, M, h, r):
         d0, t0 = ops.gemm_tn(dpre, o, with_colsum=True)
         d1, t1 = ops.gemm_tn(g, h1, with_colsum=True)
         assert torch.equal(c0, d0) and torch.equal(s0, t0) and torch.equal(c1, d1) and torch.equal(s1, t1)
+
+
+def _rot_tables(s, d, dtype, dev, offset=0):
+    pos = torch.arange(offset + s, dtype=torch.float32)
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    emb = torch.cat((pos[:, None] * inv[None, :],) * 2, dim=-1)
+    return emb.cos().to(dtype).to(dev), emb.sin().to(dtype).to(dev)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("s,b,np_,d,K,offset,force", [(64, 2, 2, 16, 64, 0, 0), (33, 3, 4, 32, 128, 2, 0), (100, 1, 2, 64, 192, 0, 0),
+                                                      (128, 4, 4, 16, 256, 0, 1), (75, 4, 8, 64, 128, 1, 1), (2048, 4, 16, 16, 1024, 0, 0)])
+def test_gemm_qkv_rotary_epilogue_equals_two_passes(ops, cuda_device, force_gemm256, dt, s, b, np_, d, K, offset, force):
+    """mm_gemm_nt_qkv_rotary (rotary embedding as the QKV GEMM's epilogue) is bit-identical to mm_gemm_nt(bias) followed by
+    mm_rotary_qk_inplace - both the 128x128 and the 256x256 kernel, ragged row counts, every fused rotary width."""
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dt]
+    hn = 64
+    torch.manual_seed(s + d)
+    x = torch.randn(s, b, K).to(dtype).to(cuda_device)
+    w = (torch.randn(np_ * 3 * hn, K) * 0.05).to(dtype).to(cuda_device)
+    bias = (torch.randn(np_ * 3 * hn) * 0.1).to(dtype).to(cuda_device)
+    cos, sin = _rot_tables(s, d, dtype, cuda_device, offset)
+    assert ops.qkv_rotary_supported(hn, d, w.size(0), K, s * b, b)
+    if force:
+        force_gemm256(1)
+    fused = ops.gemm_nt_qkv_rotary(x, w, bias, cos, sin, b, hn, d, offset)
+    two = ops.gemm_nt(x, w, bias, 1)
+    ops.rotary_qk_inplace(two.view(s, b, np_, 3 * hn), cos, sin, s, b, np_, hn, d, offset)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.view(torch.int16), two.view(torch.int16))
+    # and it really rotated something / left v alone
+    plain = ops.gemm_nt(x, w, bias, 1).view(s, b, np_, 3 * hn)
+    f4 = fused.view(s, b, np_, 3 * hn)
+    assert torch.equal(f4[..., 2 * hn:], plain[..., 2 * hn:]) and torch.equal(f4[..., d:hn], plain[..., d:hn])
+    if s > 1:
+        assert not torch.equal(f4[1:, ..., :d], plain[1:, ..., :d])
+
+
+def test_gemm_qkv_rotary_rejects_unfused_shapes(ops, cuda_device):
+    x = torch.randn(8, 2, 64, device=cuda_device).bfloat16()
+    w = torch.randn(2 * 3 * 128, 64, device=cuda_device).bfloat16()
+    bias = torch.zeros(2 * 3 * 128, device=cuda_device).bfloat16()
+    cos, sin = _rot_tables(8, 128, torch.bfloat16, cuda_device)
+    assert not ops.qkv_rotary_supported(128, 128, w.size(0), 64, 16, 2)
+    with pytest.raises(RuntimeError, match="not a fused shape"):
+        ops.gemm_nt_qkv_rotary(x, w, bias, cos, sin, 2, 128, 128)
