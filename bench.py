@@ -8,7 +8,7 @@
 One "step" = one full training step of the reference's magma_pythia_410M recipe on one synthetic micro-batch per GPU
 (4 x 2048 tokens: 1 image-prefix token + 2047 caption tokens): prefix projection + embedding + 24
 ParallelTransformerLayers with MAGMA adapters (frozen LM) + final LayerNorm + LM head + masked cross entropy,
-backward, data-parallel gradient all-reduce (RCCL), Adam on the trainable parameters.  Every matmul / attention /
+backward, data-parallel gradient all-reduce (RCCL), gradient clipping + mixed-precision Adam on the trainable parameters.  Every matmul / attention /
 norm / activation / loss kernel is this repo's HIP code (libmm_hip.so); nothing is skipped or cached.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel: the h->4h MFMA GEMM with
@@ -133,7 +133,10 @@ def main():
     model = harness.MagmaStack(cfg, dtype=torch.bfloat16, device=device)
     model.train()
     params = model.trainable_parameters()
-    opt = torch.optim.Adam(params, lr=8e-4, betas=(0.9, 0.95), eps=1e-8, fused=True)  # magma_setup.yml:38-45
+    # FusedAdam (fp32 master weights + moments) with the engine's global-norm clipping folded in: magma_setup.yml:38-45,
+    # gradient_clipping: 1.0 (magma_pythia_410M.yml:57), megatron/training.py:571-580
+    from multimodal_amd.optim import FusedAdam
+    opt = FusedAdam(params, lr=8e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
     batches = [harness.synthetic_batch(cfg, device, seed=1000 * rank + i) for i in range(4)]
     dp_group = mpu.get_data_parallel_group()
 
@@ -143,8 +146,7 @@ def main():
         loss = model(enc, tokens, labels, lmask)
         loss.backward()
         mpu.allreduce_gradients(params, group=dp_group)
-        torch.nn.utils.clip_grad_norm_(params, 1.0)  # gradient_clipping: 1.0 (magma_pythia_410M.yml:57)
-        opt.step()
+        opt.step()  # clip + Adam: two launches (csrc/optimizer.hip)
         return loss
 
     losses = []

@@ -218,6 +218,24 @@ int mm_cross_entropy_fwd(float* loss, float* lse, const void* logits, const int6
 int mm_cross_entropy_bwd(void* dlogits, const void* logits, const int64_t* labels, const float* lse,
                          const float* row_scale, int T, int V, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ optimizer step (part of the timed step)
+ * Mixed-precision Adam with global-norm gradient clipping over a list of 16-bit tensors, two launches per step.  States
+ * the update rule of the optimizer the recipe constructs (apex / DeepSpeed FusedAdam in adam_w_mode under DeepSpeed's
+ * 16-bit wrapper with fp32 master weights, megatron/training.py:571-580,659-668; gradient_clipping,
+ * configs/magma_pythia_410M.yml:57) - those libraries are not in the reference tree: parity unpinned.
+ *   params / grads : DEVICE arrays [n_tensors] of device pointers (16-bit weights / their gradients; a NULL gradient
+ *                    leaves that tensor untouched and contributes 0 to the norm);
+ *   master, exp_avg, exp_avg_sq : flat fp32 [sum of tensor sizes, each padded to a multiple of 8];
+ *   chunks : DEVICE array [nchunks] of {int32 tensor, int32 count, int64 tensor_offset, int64 flat_offset}, one per block,
+ *            count <= mm_adam_chunk_elems(), tensor_offset and flat_offset multiples of 8 elements;
+ *   partial : fp32 [nchunks] workspace; step : device int32, incremented by the call (bias correction uses the new value);
+ *   grad_norm_out : optional device float, receives the pre-clip global L2 norm; max_grad_norm <= 0 disables clipping.
+ * Deterministic (no float atomics); no allocation, no sync. */
+int mm_adam_chunk_elems(void);
+int mm_adam_step(void* const* params, const void* const* grads, float* master, float* exp_avg, float* exp_avg_sq,
+                 const void* chunks, int nchunks, float* partial, int* step, float* grad_norm_out, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, float max_grad_norm, int bias_correction, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ test-only hardware probe
  * One wave reads a [16][64] 16-bit LDS tile with ds_read_b64_tr_b16; out: [64 lanes][4].  No reference counterpart. */
 int mm_debug_probe_tr_read(void* out, const void* in, const int* row0, const int* col0, void* stream);
