@@ -115,16 +115,26 @@ def cpu_baseline(cfg, budget_s):
 
 def main():
     a = parse()
+    if os.environ.get("MM_BENCH_WATCHDOG"):  # developer aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MM_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MM_BENCH_BACKEND=gloo is a REHEARSAL switch for one-GPU boxes (RCCL refuses two ranks on one device): ranks share GPUs
+    # round-robin and gradients travel as fp32 through gloo.  The driver's multi-GPU runs use the default, RCCL ("nccl").
+    backend = os.environ.get("MM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     from multimodal_amd import harness, mpu
     if world > 1:
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     mpu.initialize_model_parallel(1)
     mpu.model_parallel_cuda_manual_seed(1234)
     cfg = harness.CONFIGS[a.config]
@@ -145,7 +155,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = model(enc, tokens, labels, lmask)
         loss.backward()
-        mpu.allreduce_gradients(params, group=dp_group)
+        mpu.allreduce_gradients(params, group=dp_group, transport_dtype=None if backend == "nccl" else torch.float32)
         opt.step()  # clip + Adam: two launches (csrc/optimizer.hip)
         return loss
 
@@ -171,7 +181,7 @@ def main():
     ops.GEMM_EVENT_PROBE = None
     losses.append(float(loss.detach()))
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
 

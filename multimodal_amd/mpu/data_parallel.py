@@ -8,8 +8,10 @@ buckets of `bucket_bytes` and averaged with one all-reduce per bucket.
 import torch
 
 
-def allreduce_gradients(params, group=None, bucket_bytes=256 << 20, average=True):
-    """In-place average (or sum) of .grad over the data-parallel group.  No-op for a single-process group."""
+def allreduce_gradients(params, group=None, bucket_bytes=256 << 20, average=True, transport_dtype=None):
+    """In-place average (or sum) of .grad over the data-parallel group.  No-op for a single-process group.
+    transport_dtype (e.g. torch.float32) up-casts the flat bucket for the wire: the fp32_allreduce option of the reference's
+    mappings (megatron/mpu/mappings.py:36-46), and what a gloo rehearsal of the multi-rank path needs for 16-bit grads."""
     if group == "single-process" or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
         return 0
     world = torch.distributed.get_world_size(group=group)
@@ -26,9 +28,18 @@ def allreduce_gradients(params, group=None, bucket_bytes=256 << 20, average=True
 
         def flush(bucket):
             flat = torch.cat([g.reshape(-1) for g in bucket]) if len(bucket) > 1 else bucket[0].reshape(-1).clone()
+            if transport_dtype is not None and flat.dtype != transport_dtype:
+                flat = flat.to(transport_dtype)
             if average:
                 flat.div_(world)  # pre-divide: keeps 16-bit sums in range
-            torch.distributed.all_reduce(flat, group=group)
+            if flat.is_cuda and torch.distributed.get_backend(group) == "gloo":
+                # gloo rehearsal of the multi-rank path on a one-GPU box (its device-tensor ring stalled there on a 55 MB
+                # bucket): stage through host memory; RCCL ("nccl") takes the device tensor directly
+                host = flat.cpu()
+                torch.distributed.all_reduce(host, group=group)
+                flat.copy_(host)
+            else:
+                torch.distributed.all_reduce(flat, group=group)
             off = 0
             for g in bucket:
                 n = g.numel()
