@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="magma_pythia_410M")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches only (no HIP-graph replay)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -150,40 +151,97 @@ def main():
     batches = [harness.synthetic_batch(cfg, device, seed=1000 * rank + i) for i in range(4)]
     dp_group = mpu.get_data_parallel_group()
 
-    def step(i):
-        enc, tokens, labels, lmask = batches[i % len(batches)]
+    # static input buffers: the captured graph reads these addresses; each step copies its synthetic batch in first
+    static = [t.clone() if t is not None else None for t in batches[0]]
+
+    def load_batch(i):
+        for dst, src in zip(static, batches[i % len(batches)]):
+            if dst is not None:
+                dst.copy_(src)
+
+    def fwd_bwd():
         opt.zero_grad(set_to_none=True)
-        loss = model(enc, tokens, labels, lmask)
+        loss = model(*static)
         loss.backward()
-        mpu.allreduce_gradients(params, group=dp_group, transport_dtype=None if backend == "nccl" else torch.float32)
-        opt.step()  # clip + Adam: two launches (csrc/optimizer.hip)
         return loss
 
-    losses = []
-    for i in range(a.warmup):
-        losses.append(float(step(i).detach()))
+    def reduce_and_update():
+        mpu.allreduce_gradients(params, group=dp_group, transport_dtype=None if backend == "nccl" else torch.float32)
+        opt.step()  # clip + Adam: two launches (csrc/optimizer.hip)
+
+    def step(i):  # eager launches
+        load_batch(i)
+        loss = fwd_bwd()
+        reduce_and_update()
+        return loss
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    losses = []
+    side = torch.cuda.Stream()  # warm-up on a side stream, as graph capture wants (allocator / autograd state settled)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(a.warmup):
+            losses.append(float(step(i).detach()))
+    torch.cuda.current_stream().wait_stream(side)
+    fence()
+
+    # ---- the step as a HIP graph: forward + backward (+ clip + Adam when there is no collective in between) captured once and
+    # replayed; with N > 1 ranks the gradient all-reduce (RCCL) and the optimizer's two launches follow the replay eagerly.
+    # Replay reproduces the eager step bit for bit (tests/test_graph_gpu.py); it removes the host's per-launch cost (~650
+    # launches per step) from the critical path.
+    graph, graph_loss, graph_err = None, None, None
+    if not a.no_graph:
+        try:
+            load_batch(0)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_loss = fwd_bwd()
+                if world == 1:
+                    opt.step()
+            fence()  # (capture launches nothing: the gradients hold no values until the first replay)
+        except Exception as e:  # fall back to eager launches and say so in the JSON line
+            graph, graph_err = None, "%s: %s" % (type(e).__name__, str(e)[:200])
+            torch.cuda.synchronize()
+
+    def graph_step(i):
+        load_batch(i)
+        graph.replay()
+        if world > 1:
+            reduce_and_update()
+        return graph_loss
+
+    def timed(fn):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            loss = fn(a.warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, loss
+
     from multimodal_amd import _lib, ops
+    dt_graph = None
+    if graph is not None:
+        for i in range(2):
+            graph_step(i)
+        dt_graph, loss = timed(graph_step)
+        losses.append(float(loss.detach()))
+    # eager launches of the same K steps, with HIP events around the roofline kernel on its launch stream
     probe = {"epilogue": _lib.EPI_BIAS_GELU_TANH if cfg["bias_gelu_fusion"] else _lib.EPI_BIAS_GELU_ERF, "events": []}
     if rank == 0:
         ops.GEMM_EVENT_PROBE = probe
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss = step(a.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
+    dt_eager, loss = timed(step)
     ops.GEMM_EVENT_PROBE = None
     losses.append(float(loss.detach()))
-    if world > 1:
-        tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = dt_graph if dt_graph is not None else dt_eager
 
     tokens_per_step = cfg["micro_batch"] * cfg["seq_length"] * world
     value = tokens_per_step * a.steps / dt
@@ -204,6 +262,12 @@ def main():
             "mfma_util_model": round(mfma_util, 4),
             "model_tflops_per_gpu": round(flops_step * a.steps / dt / 1e12, 1),
             "loss_first_last": [round(losses[0], 4) if losses else None, round(losses[-1], 4)],
+            "launch": ("hipGraph replay of the captured step (forward + backward%s), %d timed steps; the same %d steps with eager "
+                       "launches: %.3f ms/step (the roofline kernel's HIP events are recorded in those)"
+                       % (" + clip + Adam" if world == 1 else "; all-reduce + clip + Adam follow eagerly", a.steps, a.steps,
+                          dt_eager / a.steps * 1e3)) if dt_graph is not None else
+                      ("eager launches" + (" (graph capture failed: %s)" % graph_err if graph_err else "")),
+            "eager_ms_per_step": round(dt_eager / a.steps * 1e3, 3),
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

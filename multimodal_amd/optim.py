@@ -57,6 +57,7 @@ class FusedAdam:
         # pinned staging for the per-step gradient pointer table: two buffers, each reused only after the copy that read
         # it has executed (the host can run a whole step ahead of the GPU)
         self._grad_ptrs_host = [torch.zeros(len(params), dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._capture_host = torch.zeros(len(params), dtype=torch.int64).pin_memory()  # see step(): HIP-graph capture
         self._host_events = [None, None]
         self._flip = 0
         self._grad_ptrs = torch.zeros(len(params), dtype=torch.int64, device=dev)
@@ -79,8 +80,14 @@ class FusedAdam:
         g = self.param_groups[0]
         params = g["params"]
         self._held = []  # keep this step's gradient tensors alive until the next step (the launches are asynchronous)
-        self._flip ^= 1
-        host, ev = self._grad_ptrs_host[self._flip], self._host_events[self._flip]
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # the copy below becomes a memcpy node that re-reads this pinned buffer at every replay; the gradients live in
+            # the graph's private pool (same addresses every replay), so the table stays valid: a buffer of its own
+            host, ev = self._capture_host, None
+        else:
+            self._flip ^= 1
+            host, ev = self._grad_ptrs_host[self._flip], self._host_events[self._flip]
         if ev is not None:
             ev.synchronize()
         ptrs = []
@@ -95,9 +102,10 @@ class FusedAdam:
             ptrs.append(gr.data_ptr())
         host.numpy()[:] = ptrs
         self._grad_ptrs.copy_(host, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._host_events[self._flip] = ev
+        if not capturing:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._host_events[self._flip] = ev
         if self._param_ptrs.numel() != len(params):
             raise RuntimeError("FusedAdam: parameter list changed after construction")
         b1, b2 = g["betas"]

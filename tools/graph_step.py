@@ -10,12 +10,13 @@ mpu.initialize_model_parallel(1); mpu.model_parallel_cuda_manual_seed(1234)
 cfg = harness.CONFIGS["magma_pythia_410M"]
 model = harness.MagmaStack(cfg, dtype=torch.bfloat16, device=dev); model.train()
 params = model.trainable_parameters()
-opt = torch.optim.Adam(params, lr=8e-4, fused=True, capturable=True)
+from multimodal_amd.optim import FusedAdam
+opt = FusedAdam(params, lr=8e-4, betas=(0.9, 0.95), max_grad_norm=1.0)
 batch = harness.synthetic_batch(cfg, dev, seed=0)
 def step():
-    opt.zero_grad(set_to_none=False)
+    opt.zero_grad(set_to_none=True)
     loss = model(*batch); loss.backward()
-    torch.nn.utils.clip_grad_norm_(params, 1.0); opt.step()
+    opt.step()
     return loss
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
@@ -24,9 +25,9 @@ with torch.cuda.stream(s):
 torch.cuda.current_stream().wait_stream(s)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(5): step()
+for _ in range(10): step()
 torch.cuda.synchronize()
-print("eager  %.2f ms/step" % ((time.perf_counter() - t0) * 200))
+print("eager  %.2f ms/step" % ((time.perf_counter() - t0) * 100))
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     loss = step()
@@ -34,6 +35,10 @@ torch.cuda.synchronize()
 for _ in range(2): g.replay()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(5): g.replay()
+for _ in range(10): g.replay()
 torch.cuda.synchronize()
-print("graph  %.2f ms/step  loss %.4f" % ((time.perf_counter() - t0) * 200, float(loss)))
+print("graph  %.2f ms/step  loss %.4f" % ((time.perf_counter() - t0) * 100, float(loss)))
+t0 = time.perf_counter()
+for _ in range(10): step()
+torch.cuda.synchronize()
+print("eager  %.2f ms/step (again)" % ((time.perf_counter() - t0) * 100))
