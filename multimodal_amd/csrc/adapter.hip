@@ -12,22 +12,22 @@
 //              (the kernel takes W2 and W1 as stored: their tiles are staged row-major and the MFMA fragments are read
 //               TRANSPOSED from LDS with ds_read_b64_tr_b16 - no per-step W^T copies of the trainable weights)
 //
-// so one kernel template serves both.  Structure: a workgroup owns 32 token rows (256 workgroups at 8192 tokens);
-//   * eight waves (two per SIMD): wave (w & 3, w >> 2) owns a quarter of the columns and one of the two 16-row MFMA tiles;
-//   * the 32 x h block of X is staged into LDS (XOR-swizzled 16-byte chunks) in 64-column chunks that travel with the
-//     weight tiles of the first product - it is the MFMA operand of the first product AND the residual of the second; the
-//     output block is assembled in place and each finished 64-column chunk is stored while the next one is computed;
-//   * the weights (2 x 256 KiB, L2-resident, shared by every workgroup) stream through a three-buffer LDS ring in 32 steps
-//     (16 K-tiles of Wa, 16 column chunks of Wb), fetched with COALESCED 16-byte loads into registers several steps ahead
-//     (fully unrolled, so the prefetch distance is just register liveness) - fragment-shaped loads straight from global
-//     memory were tried first and are 8x more L1 accesses per instruction (one line per lane): 26 us, L1-issue-bound;
-//   * H goes through an 8 KiB LDS tile between the two products (and to HBM once, coalesced: the backward needs it);
-//   * one barrier per step; within a step the LDS write of tile s+2 and the fragment reads of tile s+1 overlap the
-//     MFMAs of tile s.  Measured (s_memtime stamps, -DMM_AD_STAMP diagnostic build): prologue 4.8k cycles, 16 steps of the
-//     first product 10.8k, 16 chunks of the second 12.6k - ~700 cycles per step against a 470-cycle L2 -> CU fill bound
-//     (16 KiB per step): the LDS pipe (ds_write of the tile + fragment reads, ~400 cycles per step) is the next limit.
+// so one kernel template serves both.  Structure: a workgroup owns 32 token rows (256 workgroups at 8192 tokens), eight
+// waves (two per SIMD): wave (w & 3, w >> 2) owns a quarter of the columns and one of the two 16-row MFMA tiles;
+//   * the 32 x h block of X lives in LDS - it is the MFMA operand of the first product AND the residual of the second; it
+//     arrives in 64-column chunks that travel with the weight tiles, the output block is assembled in place and each
+//     finished 64-column chunk is stored (full 128-byte lines) while the next one is computed;
+//   * the weights (2 x 256 KiB, L2-resident, shared by every workgroup) stream through an LDS ring in 32 steps (16 K-tiles of
+//     Wa, 16 column chunks of Wb), one barrier per step; H goes through an 8 KiB LDS tile between the two products (and to HBM
+//     once, coalesced: the backward needs it);
+//   * backward: the operands are W2^T and W1^T of the weights AS STORED: tiles are staged [k][n] and the MFMA fragments
+//     are read transposed with ds_read_b64_tr_b16 (32-byte segments XOR-swizzled so the 8 rows a half-wave touches fall in
+//     different banks) - no per-step W^T copies of the trainable weights.
 // Rounding points are exactly those of the unfused path (mm_gemm_nt with MM_EPI_BIAS_RELU / MM_EPI_BIAS + residual /
 // MM_EPI_RELU_BWD / residual), and each output element's K-order is the same, so the results are bit-identical to it.
+// History (device time per launch at 8192 x 1024 x 128): two skinny GEMMs 27 us -> register-staged ring, 4 waves 19.2 ->
+// 8 waves, X / output streamed per chunk 16.8 -> LDS-DMA ring (below) 14.6.  Stamps (-DMM_AD_STAMP): prologue 3.2k cycles,
+// first product 490 cycles per step, second 720 (its per-chunk barrier + in-place epilogue chain is the next thing to cut).
 #include "gemm_common.h"
 #include "mfma32.h"
 
@@ -36,182 +36,197 @@ namespace mm {
 constexpr int AD_BM = 32;
 constexpr int AD_THREADS = 512;  // 8 waves: two per SIMD, so one wave's LDS / L2 latency hides behind its partner's MFMAs
 
+// =====================================================================================================================
+// bottleneck_dma_k - the weight tiles and the X chunks are staged global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip and no ds_write issue cost), a five-buffer
+// ring filled three steps ahead, and EVERY LDS access written as inline asm: the compiler orders any LDS access it can see
+// behind all in-flight LDS-DMA (s_waitcnt vmcnt(0)), which would drain the ring every step.  The waits are therefore
+// counted by hand: `younger()` replays the wave's VMEM issue order at compile time (the kernel is fully unrolled) and
+// returns how many operations were issued after a tile's last DMA, i.e. the vmcnt that proves the tile has landed.
+// LDS images: weight tiles [n][k] rows of 128 / 2R bytes with the XOR chunk swizzles of the fragment-read formulas below
+// (applied on the DMA SOURCE address); the X block is chunk-major ([chunk][32 rows][128 B], the GEMM kernels' A-tile
+// image) because one DMA instruction writes 1 KiB of contiguous LDS.
+constexpr int AD_PD = 3;           // tiles in flight beyond the one being published
+constexpr int AD_NB = AD_PD + 2;   // ring buffers
+
+constexpr int ad_waitcnt_imm(int vm, int lgkm) { return (vm & 0xF) | (7 << 4) | ((lgkm & 0xF) << 8) | (((vm >> 4) & 3) << 14); }
+#define AD_WAIT(vm, lgkm)                                          \
+    do {                                                           \
+        __builtin_amdgcn_s_waitcnt(ad_waitcnt_imm(vm, lgkm));      \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    } while (0)
+
+__device__ __forceinline__ u32x4 ad_rd16(uint32_t a) {
+    u32x4 d;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ u32x2 ad_rd8(uint32_t a) {
+    u32x2 d;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ u32x2 ad_rd8_tr(uint32_t a) {
+    u32x2 d;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ void ad_wr8(uint32_t a, u32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void ad_wr16(uint32_t a, u32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void ad_barrier() {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// VMEM operations a wave has issued AFTER the last DMA instruction of tile `tile`, counted at the end of step `step`
+// (step -1 = right after the prologue).  Issue order per wave: prologue tiles 0..PD; then in step s the DMA of tile
+// s+PD+1, then that step's global store (H tile in step S1, output chunk c-1 in step S1+c).  A tile = [one X-chunk
+// instruction if the wave is an X mover and the tile belongs to the first product] + NW weight instructions.
+constexpr int ad_younger(int tile, int step, int NW, int S1, int S, bool mover, bool hstore) {
+    int count = -1;  // -1: the tile's DMA not seen yet
+    auto emit_tile = [&](int t) {
+        const int ops = NW + ((mover && t < S1) ? 1 : 0);
+        if (count >= 0) count += ops;
+        if (t == tile) count = 0;
+    };
+    for (int t = 0; t <= AD_PD; ++t)
+        if (t < S) emit_tile(t);
+    for (int s = 0; s <= step; ++s) {
+        if (s + AD_PD + 1 < S) emit_tile(s + AD_PD + 1);
+        const bool st = (s == S1) ? hstore : (s > S1 ? mover : false);
+        if (st && count >= 0) count += 1;
+    }
+    return count < 0 ? 0 : count;
+}
+
 template <typename T, int HID, int R, int MODE>  // MODE 0: forward, 1: backward (data gradient)
-__global__ __launch_bounds__(AD_THREADS) void bottleneck_k(u16* __restrict__ Y, u16* __restrict__ Hout, const u16* __restrict__ X,
-                                                    const u16* __restrict__ Wa, const u16* __restrict__ ba,
-                                                    const u16* __restrict__ Wb, const u16* __restrict__ bb,
-                                                    const u16* __restrict__ Hsaved, int rows) {
+__global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__ Y, u16* __restrict__ Hout, const u16* __restrict__ X,
+                                                               const u16* __restrict__ Wa, const u16* __restrict__ ba,
+                                                               const u16* __restrict__ Wb, const u16* __restrict__ bb,
+                                                               const u16* __restrict__ Hsaved, int rows) {
     typedef typename Mfma<T>::frag frag;
-    constexpr int XROW = HID * 2, HROW = R * 2;     // bytes per LDS row of the X block / the H tile
-    constexpr int XCPR = HID / 8, HCPR = R / 8;     // 16-byte chunks per row
-    constexpr int HSW = HCPR >= 16 ? 15 : HCPR - 1; // swizzle mask for rows of HCPR chunks
-    constexpr int NI1 = R / 64;                     // first product: wave (w & 3, w >> 2) owns R/4 columns = NI1 MFMA tiles of 16 rows
-    constexpr int S1 = HID / 64;                    // ... in S1 steps of 64 k (one Wa tile [R][64] each)
-    constexpr int CH2 = 64;                         // second product: chunks of CH2 output columns (Wb rows), 16 per wave
-    constexpr int S2 = HID / CH2;
-    constexpr int NI2 = CH2 / 64;                   // MFMA tiles per wave per chunk
-    constexpr int KS2 = R / 32;
-    constexpr int L1N = R * 8 / AD_THREADS;         // 16-byte loads per thread per Wa tile
-    constexpr int L2N = CH2 * HCPR / AD_THREADS;    // ... per Wb chunk
-    constexpr int LMAX = L1N > L2N ? L1N : L2N;
-    constexpr int RING = (R * 128 > CH2 * HROW) ? R * 128 : CH2 * HROW;  // bytes per ring buffer
-    constexpr int D1 = 8;                           // prefetch distance in steps (Wa tiles and Wb chunks alike): ~128 KiB in flight per CU
-    __shared__ __attribute__((aligned(16))) char smem[AD_BM * XROW + AD_BM * HROW + 3 * RING + HID * 2];
-    char* Xs = smem;
-    char* Hs = smem + AD_BM * XROW;
-    char* Ws = Hs + AD_BM * HROW;
-    char* Bs = Ws + 3 * RING;  // bb staged once (forward)
-    const int tid = threadIdx.x, wave = (tid >> 6) & 3, wmi = tid >> 8, lane = tid & 63, frow = lane & 15, fq = lane >> 4;
+    constexpr int HROW = R * 2, HCPR = R / 8;
+    constexpr int HSW = HCPR >= 16 ? 15 : HCPR - 1;
+    constexpr int NI1 = R / 64, S1 = HID / 64, S2 = HID / 64, S = S1 + S2, KS2 = R / 32;
+    constexpr int RING = R * 128;              // bytes per tile: Wa tile [R][64] / [64][R], Wb chunk [64][R] / [R][64]
+    constexpr int NW = RING / 1024 / 8;        // DMA instructions per wave per tile
+    static_assert(RING % 8192 == 0 && NW >= 1, "a tile must be a whole number of DMA instructions per wave");
+    constexpr int XS_BYTES = S1 * 4096, HS_BYTES = AD_BM * HROW;
+    constexpr int T1SEG = HROW / 32;
+    constexpr bool HSTORE_ALL = (AD_BM * HCPR == AD_THREADS);  // does every wave store a piece of the H tile?
+    static_assert(AD_BM * HCPR == AD_THREADS || AD_BM * HCPR == 256, "H tile store: all waves or exactly the X movers");
+    __shared__ __attribute__((aligned(1024))) char smem[XS_BYTES + HS_BYTES + AD_NB * RING + HID * 2];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+    const uint32_t XS = lds0, HS = lds0 + XS_BYTES, WS = HS + HS_BYTES, BS = WS + AD_NB * RING;
+    const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fq = lane >> 4;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar: uniform branches, scalar LDS bases
+    const int wave = w8 & 3, wmi = w8 >> 2;
     const int m0 = blockIdx.x * AD_BM;
+    const int mrow = wmi * 16 + frow;
+    const bool xmover = w8 < 4;
 #ifdef MM_AD_STAMP
     const uint64_t st0 = __builtin_amdgcn_s_memtime();
     uint64_t st1 = 0, st2 = 0;
 #endif
-
-    // ---- weight staging: step s < S1 is Wa tile s, step S1 + c is Wb chunk c
-    // Forward: Wa = W1 [R][HID] and Wb = W2 [HID][R] are K-contiguous: tiles [n][k], fragments by ds_read_b128.
-    // Backward: the operands are W2^T and W1^T of the weights as stored, so a tile is staged as [k][n] (rows of the stored
-    // matrix) and fragments are read transposed; 32-byte segments are XOR-swizzled so that the 8 rows one half-wave
-    // touches per ds_read_b64_tr_b16 fall in different banks.
-    constexpr int T1SEG = HROW / 32;  // backward Wa tile: [64 k][R n], row = HROW bytes
     auto tsw = [](int row, int nseg) { return nseg >= 8 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); };
-    u32x4 wreg[S1 + S2][LMAX];
-    auto w_issue = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if constexpr (s < S1) {
-#pragma unroll
-            for (int i = 0; i < L1N; ++i) {
-                const int c = tid + AD_THREADS * i;
-                if (MODE == 0) {
-                    const int row = c >> 3, ch = c & 7;
-                    wreg[s][i] = *reinterpret_cast<const u32x4*>(Wa + (size_t)row * HID + s * 64 + ch * 8);
-                } else {  // Wa = stored W2 [HID][R]: rows 64s .. 64s+63
-                    const int row = c / HCPR, ch = c % HCPR;
-                    wreg[s][i] = *reinterpret_cast<const u32x4*>(Wa + (size_t)(s * 64 + row) * R + ch * 8);
-                }
-            }
-        } else if constexpr (s < S1 + S2) {
-#pragma unroll
-            for (int i = 0; i < L2N; ++i) {
-                const int c = tid + AD_THREADS * i;
-                if (MODE == 0) {
-                    const int row = c / HCPR, ch = c % HCPR;
-                    wreg[s][i] = *reinterpret_cast<const u32x4*>(Wb + (size_t)((s - S1) * CH2 + row) * R + ch * 8);
-                } else {  // Wb = stored W1 [R][HID]: all R rows, columns CH2*c .. +CH2-1
-                    const int row = c >> 3, ch = c & 7;
-                    wreg[s][i] = *reinterpret_cast<const u32x4*>(Wb + (size_t)row * HID + (s - S1) * CH2 + ch * 8);
-                }
-            }
-        }
-    };
-    auto w_store = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        char* buf = Ws + (s % 3) * RING;
-        if constexpr (s >= S1 + S2) {
-        } else if constexpr (s < S1) {
-#pragma unroll
-            for (int i = 0; i < L1N; ++i) {
-                const int c = tid + AD_THREADS * i;
-                if (MODE == 0) {
-                    const int row = c >> 3, ch = c & 7;
-                    *reinterpret_cast<u32x4*>(buf + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = wreg[s][i];
-                } else {
-                    const int row = c / HCPR, ch = c % HCPR;
-                    *reinterpret_cast<u32x4*>(buf + row * HROW + (((ch >> 1) ^ tsw(row, T1SEG)) << 5) + ((ch & 1) << 4)) = wreg[s][i];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < L2N; ++i) {
-                const int c = tid + AD_THREADS * i;
-                if (MODE == 0) {
-                    const int row = c / HCPR, ch = c % HCPR;
-                    *reinterpret_cast<u32x4*>(buf + row * HROW + ((ch ^ (row & HSW)) << 4)) = wreg[s][i];
-                } else {  // [R k][CH2 n], rows of 128 bytes (4 segments)
-                    const int row = c >> 3, ch = c & 7;
-                    *reinterpret_cast<u32x4*>(buf + row * 128 + (((ch >> 1) ^ tsw(row, 4)) << 5) + ((ch & 1) << 4)) = wreg[s][i];
-                }
-            }
-        }
-    };
-    // transposed fragment of a [k][n] tile (row bytes rb, nseg 32-byte segments per row): lane (i = lane&15, g = lane>>4)
-    // gets tile[kb + 8g + j][n0 + i], j = 0..7 (lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3)
-    auto tr_frag16 = [&](const char* buf, int rb, int nseg, int kb, int n0) {
-        const int q = frow >> 2, pp = frow & 3;
-        const int r0 = kb + 8 * fq + q, r1 = r0 + 4;
-        const char* pa = buf + r0 * rb + (((n0 >> 4) ^ tsw(r0, nseg)) << 5) + 8 * pp;
-        const char* pb = buf + r1 * rb + (((n0 >> 4) ^ tsw(r1, nseg)) << 5) + 8 * pp;
-        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
-        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
-        const s16x8 v = s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        frag f;
-        __builtin_memcpy(&f, &v, 16);
-        return f;
-    };
 
-    // ---- small operands first: a load that is issued late is waited for with vmcnt(0), i.e. it drains the whole weight
-    // prefetch queue behind which it sits (vmcnt retires in order) - so nothing but weight tiles is loaded after this point.
+    // ---- small operands first (they sit in front of every DMA in the in-order VMEM queue)
     const int nb1 = wave * (R / 4);
-    const int mrow = wmi * 16 + frow;  // the block row this lane owns in both products (wave half wmi = MFMA row tile)
-    u32x2 small1[NI1];     // forward: b1 of the lane's H columns; backward: the saved H values of (mrow, those columns)
+    u32x2 small1[NI1];
     u32x4 bbreg = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int ni = 0; ni < NI1; ++ni) {
         const int n0 = nb1 + ni * 16 + fq * 4;
+        if (MODE == 0) small1[ni] = *reinterpret_cast<const u32x2*>(ba + n0);
+        else small1[ni] = *reinterpret_cast<const u32x2*>(Hsaved + (size_t)min(m0 + mrow, rows - 1) * R + n0);
+    }
+    if (MODE == 0 && tid < HID / 8) bbreg = *reinterpret_cast<const u32x4*>(bb + tid * 8);
+
+    // ---- per-lane DMA sources.  Physical 16-byte slot P of a tile image holds logical piece (row, ch) with the swizzle of
+    // the matching read formula below; instruction j of a tile fills slots 64j .. 64j+63.
+    const u16* wa_src[NW];
+    const u16* wb_src[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int j = w8 * NW + i;
         if (MODE == 0) {
-            small1[ni] = *reinterpret_cast<const u32x2*>(ba + n0);
+            {   // Wa = W1 [R][HID]: tile s = columns 64s..: image [R rows][128 B], piece ^ ((row >> 1) & 7)
+                const int row = 8 * j + (lane >> 3), q = lane & 7;
+                wa_src[i] = Wa + (size_t)row * HID + ((q ^ ((row >> 1) & 7)) << 3);
+            }
+            {   // Wb = W2 [HID][R]: chunk c = rows 64c..: image [64 rows][HROW], piece ^ (row & HSW)
+                const int row = (1024 / HROW) * j + lane / HCPR, q = lane % HCPR;
+                wb_src[i] = Wb + (size_t)row * R + ((q ^ (row & HSW)) << 3);
+            }
         } else {
-            small1[ni] = *reinterpret_cast<const u32x2*>(Hsaved + (size_t)min(m0 + mrow, rows - 1) * R + n0);
+            {   // Wa = stored W2 [HID][R]: tile s = rows 64s..: image [64 k][HROW], 32-byte segments ^ tsw(row, T1SEG)
+                const int row = (1024 / HROW) * j + lane / HCPR, q = lane % HCPR;
+                wa_src[i] = Wa + (size_t)row * R + (((((q >> 1) ^ tsw(row, T1SEG)) << 1) | (q & 1)) << 3);
+            }
+            {   // Wb = stored W1 [R][HID]: chunk c = columns 64c..: image [R k][128 B], segments ^ tsw(row, 4)
+                const int row = 8 * j + (lane >> 3), q = lane & 7;
+                wb_src[i] = Wb + (size_t)row * HID + (((((q >> 1) ^ tsw(row, 4)) << 1) | (q & 1)) << 3);
+            }
         }
     }
-    if (MODE == 0 && tid < XCPR) bbreg = *reinterpret_cast<const u32x4*>(bb + tid * 8);
-
-    // ---- X block: staged per 64-column chunk, chunk s travelling with weight tile s (issued D1 steps ahead, written to
-    // LDS two steps ahead, published by the same barrier): the first product starts when the FIRST chunk has arrived, not
-    // the whole 64 KiB block.  Thread -> (row tid>>3, 16-byte piece tid&7 of the chunk): 8 lanes cover one 128-byte line.
-    // Waves 0-3 move the X chunks in and the output chunks out (256 pieces per chunk); waves 4-7 only move weights.
-    static_assert(AD_BM * 8 == 256, "one 16-byte piece per thread of the first four waves per X chunk");
-    u32x4 xr[S1];
-    const bool xmover = tid < 256;  // wave-uniform
+    constexpr size_t WA_STRIDE = (MODE == 0) ? 64 : (size_t)64 * R;   // elements between consecutive Wa tiles
+    constexpr size_t WB_STRIDE = (MODE == 0) ? (size_t)64 * R : 64;  // ... Wb chunks
+    // X chunk s = columns 64s.. of the 32 rows: image [32 rows][128 B], piece ^ ((row >> 1) & 7); wave w < 4 fills rows 8w..8w+7
     const int xrow = (tid >> 3) & 31, xpc = tid & 7;
-    const u16* xsrc = X + (size_t)min(m0 + xrow, rows - 1) * HID + xpc * 8;
-    auto x_issue = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if constexpr (s < S1)
-            if (xmover) xr[s] = *reinterpret_cast<const u32x4*>(xsrc + s * 64);
-    };
-    auto x_store = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if constexpr (s < S1)
-            if (xmover) *reinterpret_cast<u32x4*>(Xs + xrow * XROW + (((s * 8 + xpc) ^ (xrow & 15)) << 4)) = xr[s];
-    };
-    static_for<0, D1>([&](auto sc) {
-        x_issue(sc);
-        w_issue(sc);
-    });
-    if (MODE == 0 && tid < XCPR) *reinterpret_cast<u32x4*>(Bs + tid * 16) = bbreg;
-
-    // ---- first product: H[32, R], wave w owns columns [w*R/4, (w+1)*R/4)
-    // Ring protocol (3 buffers): during step s the wave (1) writes the tile of step s+2, (2) reads the FRAGMENTS of step
-    // s+1 into registers, (3) runs the MFMAs of step s on fragments it read one step earlier - with one wave per SIMD
-    // nothing else hides the LDS latency - then one barrier: it publishes the write of (1) and retires the reads of (2),
-    // whose buffer is rewritten in step s+2.
-    f32x4 acc1[NI1];
+    const u16* x_src = X + (size_t)min(m0 + xrow, rows - 1) * HID + ((xpc ^ ((xrow >> 1) & 7)) << 3);
+    auto fill = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (t < S) {
+            if constexpr (t < S1) {
+                if (xmover)
+                    __builtin_amdgcn_global_load_lds((const void*)(x_src + t * 64), (lds_void*)(smem + t * 4096 + w8 * 1024), 16, 0, 0);
+            }
+            char* buf = smem + XS_BYTES + HS_BYTES + (t % AD_NB) * RING + w8 * NW * 1024;
 #pragma unroll
-    for (int i = 0; i < NI1; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    frag FA[S1][2], FB[S1][2][NI1], FB2[S2][KS2][NI2];
-    auto frags1 = [&](auto sc) {  // fragments of first-product step s
+            for (int i = 0; i < NW; ++i) {
+                const u16* src;
+                if constexpr (t < S1) src = wa_src[i] + (size_t)t * WA_STRIDE;
+                else src = wb_src[i] + (size_t)(t - S1) * WB_STRIDE;
+                __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(buf + i * 1024), 16, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the DMA block where the wait arithmetic (ad_younger) assumes it is
+    };
+    auto wait_tile = [&](auto tc, auto sc) {  // tile `t` landed (this wave's share), counted at the end of step `st`; + all LDS ops
+        constexpr int t = decltype(tc)::value, st = decltype(sc)::value;
+        if constexpr (t < S) {
+            constexpr int ym = ad_younger(t, st, NW, S1, S, true, true), yo = ad_younger(t, st, NW, S1, S, false, HSTORE_ALL);
+            if (xmover) AD_WAIT(ym, 0);
+            else AD_WAIT(yo, 0);
+        } else {
+            AD_WAIT(63, 0);
+        }
+    };
+
+    static_for<0, AD_PD + 1>([&](auto tc) { fill(tc); });
+    if (MODE == 0 && tid < HID / 8) ad_wr16(BS + tid * 16, bbreg);
+
+    // transposed fragment of a [k][n] tile image (row bytes rb, nseg 32-byte segments per row): lane (i = lane&15, g = lane>>4)
+    // gets tile[kb + 8g + j][n0 + i], j = 0..7 (lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3)
+    auto tr_frag16 = [&](uint32_t buf, int rb, int nseg, int kb, int n0) {
+        const int q = frow >> 2, pp = frow & 3;
+        const int r0 = kb + 8 * fq + q, r1 = r0 + 4;
+        const u32x2 a = ad_rd8_tr(buf + r0 * rb + (((n0 >> 4) ^ tsw(r0, nseg)) << 5) + 8 * pp);
+        const u32x2 b = ad_rd8_tr(buf + r1 * rb + (((n0 >> 4) ^ tsw(r1, nseg)) << 5) + 8 * pp);
+        return u32x4{a[0], a[1], b[0], b[1]};
+    };
+    u32x4 FA[S1][2], FB[S1][2][NI1], FB2[S2][KS2];
+    auto frags1 = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         if constexpr (s < S1) {
-            const char* buf = Ws + (s % 3) * RING;
+            const uint32_t buf = WS + (s % AD_NB) * RING;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                FA[s][kk] = *reinterpret_cast<const frag*>(Xs + mrow * XROW + (((s * 8 + kk * 4 + fq) ^ frow) << 4));
+                FA[s][kk] = ad_rd16(XS + s * 4096 + mrow * 128 + (((kk * 4 + fq) ^ ((mrow >> 1) & 7)) << 4));
 #pragma unroll
                 for (int ni = 0; ni < NI1; ++ni) {
                     if (MODE == 0) {
                         const int n = nb1 + ni * 16 + frow;
-                        FB[s][kk][ni] = *reinterpret_cast<const frag*>(buf + n * 128 + (((kk * 4 + fq) ^ ((n >> 1) & 7)) << 4));
+                        FB[s][kk][ni] = ad_rd16(buf + n * 128 + (((kk * 4 + fq) ^ ((n >> 1) & 7)) << 4));
                     } else {
                         FB[s][kk][ni] = tr_frag16(buf, HROW, T1SEG, kk * 32, nb1 + ni * 16);
                     }
@@ -219,118 +234,115 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_k(u16* __restrict__ Y, 
             }
         }
     };
-    auto frags2 = [&](auto cc) {  // weight fragments of second-product chunk c
+    auto frags2 = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
         if constexpr (c < S2) {
-            const char* buf = Ws + ((S1 + c) % 3) * RING;
+            const uint32_t buf = WS + ((S1 + c) % AD_NB) * RING;
 #pragma unroll
-            for (int ks = 0; ks < KS2; ++ks)
-#pragma unroll
-                for (int ni = 0; ni < NI2; ++ni) {
-                    if (MODE == 0) {
-                        const int n = wave * (CH2 / 4) + ni * 16 + frow;  // row of the chunk
-                        FB2[c][ks][ni] = *reinterpret_cast<const frag*>(buf + n * HROW + (((ks * 4 + fq) ^ (n & HSW)) << 4));
-                    } else {
-                        FB2[c][ks][ni] = tr_frag16(buf, 128, 4, ks * 32, wave * (CH2 / 4) + ni * 16);
-                    }
+            for (int ks = 0; ks < KS2; ++ks) {
+                if (MODE == 0) {
+                    const int n = wave * 16 + frow;
+                    FB2[c][ks] = ad_rd16(buf + n * HROW + (((ks * 4 + fq) ^ (n & HSW)) << 4));
+                } else {
+                    FB2[c][ks] = tr_frag16(buf, 128, 4, ks * 32, wave * 16);
                 }
+            }
         }
     };
-    x_store(std::integral_constant<int, 0>{});
-    w_store(std::integral_constant<int, 0>{});
-    x_store(std::integral_constant<int, 1>{});
-    w_store(std::integral_constant<int, 1>{});
-    __syncthreads();
+
+    // ---- first product
+    f32x4 acc1[NI1];
+#pragma unroll
+    for (int i = 0; i < NI1; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wait_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, -1>{});  // tiles 0 and 1 (and the bias image)
+    ad_barrier();
 #ifdef MM_AD_STAMP
     st1 = __builtin_amdgcn_s_memtime();
 #endif
     frags1(std::integral_constant<int, 0>{});
+    AD_WAIT(63, 0);
     static_for<0, S1>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        x_store(std::integral_constant<int, s + 2>{});
-        w_store(std::integral_constant<int, s + 2>{});
-        static_for<s + D1, s + D1 + 1>([&](auto nx) {  // (a no-op past the last step)
-            x_issue(nx);
-            w_issue(nx);
-        });
         frags1(std::integral_constant<int, s + 1>{});
         if constexpr (s + 1 == S1) frags2(std::integral_constant<int, 0>{});
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int ni = 0; ni < NI1; ++ni) acc1[ni] = Mfma<T>::run(FB[s][kk][ni], FA[s][kk], acc1[ni]);
-        if constexpr (s + 1 < S1) __syncthreads();  // (the last step's barrier comes after the H tile is written)
+            for (int ni = 0; ni < NI1; ++ni)
+                acc1[ni] = Mfma<T>::run(__builtin_bit_cast(frag, FB[s][kk][ni]), __builtin_bit_cast(frag, FA[s][kk]), acc1[ni]);
+        fill(std::integral_constant<int, s + AD_PD + 1>{});  // issued behind the MFMAs: the DMA issue slots overlap their execution
+        if constexpr (s + 1 == S1) {  // the H tile: lane holds H[mrow][n0 .. n0+3], n0 = nb1 + ni*16 + fq*4
+#pragma unroll
+            for (int ni = 0; ni < NI1; ++ni) {
+                const int n0 = nb1 + ni * 16 + fq * 4;
+                float o[4], sv[4];
+                unpack4<T>(small1[ni], sv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = (MODE == 0) ? fmaxf(rnd<T>(acc1[ni][j] + sv[j]), 0.f) : (sv[j] > 0.f ? acc1[ni][j] : 0.f);
+                ad_wr8(HS + mrow * HROW + (((n0 >> 3) ^ (mrow & HSW)) << 4) + (fq & 1) * 8, u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])});
+            }
+        }
+        wait_tile(std::integral_constant<int, s + 2>{}, sc);
+        ad_barrier();
     });
-    // lane holds H[mrow][n0 .. n0+3], n0 = nb1 + ni*16 + fq*4
-#pragma unroll
-    for (int ni = 0; ni < NI1; ++ni) {
-        const int n0 = nb1 + ni * 16 + fq * 4;
-        float o[4], sv[4];
-        unpack4<T>(small1[ni], sv);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            o[j] = (MODE == 0) ? fmaxf(rnd<T>(acc1[ni][j] + sv[j]), 0.f) : (sv[j] > 0.f ? acc1[ni][j] : 0.f);
-        *reinterpret_cast<u32x2*>(Hs + mrow * HROW + (((n0 >> 3) ^ (mrow & HSW)) << 4) + (fq & 1) * 8) =
-            u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
-    }
 
-    __syncthreads();  // publishes the H tile (and retires the last Wa tile's fragment reads)
 #ifdef MM_AD_STAMP
     st2 = __builtin_amdgcn_s_memtime();
 #endif
-
-    // ---- second product: Y[32, HID] = H Wb^T (+ bb) + X in S2 chunks of CH2 columns; wave w owns 16 columns of each chunk
-    frag fh[KS2];
-#pragma unroll
-    for (int ks = 0; ks < KS2; ++ks)
-        fh[ks] = *reinterpret_cast<const frag*>(Hs + mrow * HROW + (((ks * 4 + fq) ^ (frow & HSW)) << 4));
-    // H to HBM, 16 bytes per lane, full rows
-    static_assert(AD_BM * HCPR <= AD_THREADS, "one 16-byte piece of the H tile per thread");
-    {
-        const int row = tid / HCPR, ch = tid % HCPR;
-        if (tid < AD_BM * HCPR && m0 + row < rows)
-            *reinterpret_cast<u32x4*>(Hout + (size_t)(m0 + row) * R + ch * 8) =
-                *reinterpret_cast<const u32x4*>(Hs + row * HROW + ((ch ^ (row & HSW)) << 4));
-    }
-    // a finished 64-column chunk of the output block is stored while the next chunk is computed (one 16-byte piece per
-    // thread, 8 lanes per 128-byte line) instead of the whole 64 KiB block after the last chunk
-    static_assert(CH2 == 64, "y_store pieces assume 64-column chunks");
-    auto y_store = [&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        if (xmover && m0 + xrow < rows)
-            *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + xrow) * HID + c * CH2 + xpc * 8) =
-                *reinterpret_cast<const u32x4*>(Xs + xrow * XROW + (((c * 8 + xpc) ^ (xrow & 15)) << 4));
-    };
+    // ---- second product: wave (wave, wmi) owns 16 columns of each 64-column chunk for its 16 rows
+    u32x4 fh[KS2];
     static_for<0, S2>([&](auto cc) {
         constexpr int c = decltype(cc)::value, s = S1 + c;
-        w_store(std::integral_constant<int, s + 2>{});
-        static_for<s + D1, s + D1 + 1>([&](auto nx) { w_issue(nx); });
-        frags2(std::integral_constant<int, c + 1>{});
-        if constexpr (c > 0) y_store(std::integral_constant<int, c - 1>{});  // final since the previous step's barrier
-        f32x4 acc2[NI2];
+        u32x4 hv = u32x4{0u, 0u, 0u, 0u}, yv = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (c == 0) {
 #pragma unroll
-        for (int i = 0; i < NI2; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < KS2; ++ks) fh[ks] = ad_rd16(HS + mrow * HROW + (((ks * 4 + fq) ^ (frow & HSW)) << 4));
+            if (tid < AD_BM * HCPR) {
+                const int row = tid / HCPR, ch = tid % HCPR;
+                hv = ad_rd16(HS + row * HROW + ((ch ^ (row & HSW)) << 4));
+            }
+        }
+        frags2(std::integral_constant<int, c + 1>{});
+        if constexpr (c > 0) {
+            if (xmover) yv = ad_rd16(XS + (c - 1) * 4096 + xrow * 128 + ((xpc ^ ((xrow >> 1) & 7)) << 4));
+        }
+        const int n0 = c * 64 + wave * 16 + fq * 4;
+        const uint32_t xaddr = XS + c * 4096 + mrow * 128 + (((wave * 2 + (fq >> 1)) ^ ((mrow >> 1) & 7)) << 4) + (fq & 1) * 8;
+        const u32x2 xv = ad_rd8(xaddr);  // each X element is read and replaced by the one lane that owns it
+        u32x2 bvr = u32x2{0u, 0u};
+        if (MODE == 0) bvr = ad_rd8(BS + n0 * 2);
+        if constexpr (c == 0) AD_WAIT(63, 0);  // fh (later chunks: everything these MFMAs read landed before the last barrier)
+        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks)
-#pragma unroll
-            for (int ni = 0; ni < NI2; ++ni) acc2[ni] = Mfma<T>::run(FB2[c][ks][ni], fh[ks], acc2[ni]);
-#pragma unroll
-        for (int ni = 0; ni < NI2; ++ni) {
-            const int n0 = c * CH2 + wave * (CH2 / 4) + ni * 16 + fq * 4;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (MODE == 0) unpack4<T>(*reinterpret_cast<const u32x2*>(Bs + n0 * 2), bv);
-            u32x2* px = reinterpret_cast<u32x2*>(Xs + mrow * XROW + (((n0 >> 3) ^ (mrow & 15)) << 4) + (fq & 1) * 8);
-            const u32x2 xv = *px;  // each X element is read and replaced by the one lane that owns it
-            float o[4];
-            o[0] = rnd<T>(acc2[ni][0] + bv[0]) + to_f32<T>((u16)(xv[0] & 0xffffu));
-            o[1] = rnd<T>(acc2[ni][1] + bv[1]) + to_f32<T>((u16)(xv[0] >> 16));
-            o[2] = rnd<T>(acc2[ni][2] + bv[2]) + to_f32<T>((u16)(xv[1] & 0xffffu));
-            o[3] = rnd<T>(acc2[ni][3] + bv[3]) + to_f32<T>((u16)(xv[1] >> 16));
-            *px = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+            acc2 = Mfma<T>::run(__builtin_bit_cast(frag, FB2[c][ks]), __builtin_bit_cast(frag, fh[ks]), acc2);
+        fill(std::integral_constant<int, s + AD_PD + 1>{});
+        AD_WAIT(63, 0);  // xv, bvr, yv, hv, the next chunk's fragments
+        if constexpr (c == 0) {
+            if (tid < AD_BM * HCPR) {
+                const int row = tid / HCPR, ch = tid % HCPR;
+                if (m0 + row < rows) *reinterpret_cast<u32x4*>(Hout + (size_t)(m0 + row) * R + ch * 8) = hv;
+            }
+        } else {
+            if (xmover && m0 + xrow < rows) *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + xrow) * HID + (c - 1) * 64 + xpc * 8) = yv;
         }
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        float bv[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        if (MODE == 0) unpack4<T>(bvr, bv);
+        o[0] = rnd<T>(acc2[0] + bv[0]) + to_f32<T>((u16)(xv[0] & 0xffffu));
+        o[1] = rnd<T>(acc2[1] + bv[1]) + to_f32<T>((u16)(xv[0] >> 16));
+        o[2] = rnd<T>(acc2[2] + bv[2]) + to_f32<T>((u16)(xv[1] & 0xffffu));
+        o[3] = rnd<T>(acc2[3] + bv[3]) + to_f32<T>((u16)(xv[1] >> 16));
+        ad_wr8(xaddr, u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])});
+        wait_tile(std::integral_constant<int, s + 2>{}, std::integral_constant<int, s>{});
+        ad_barrier();
     });
-    y_store(std::integral_constant<int, S2 - 1>{});
+    if (xmover) {
+        const u32x4 yv = ad_rd16(XS + (S2 - 1) * 4096 + xrow * 128 + ((xpc ^ ((xrow >> 1) & 7)) << 4));
+        AD_WAIT(63, 0);
+        if (m0 + xrow < rows) *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + xrow) * HID + (S2 - 1) * 64 + xpc * 8) = yv;
+    }
 #ifdef MM_AD_STAMP
     {
         const uint64_t st3 = __builtin_amdgcn_s_memtime();
@@ -349,9 +361,9 @@ static int launch_bottleneck(void* Y, void* Hout, const void* X, const void* Wa,
     dim3 grid((rows + AD_BM - 1) / AD_BM), block(AD_THREADS);
 #define MM_AD_CASE(HID, RR)                                                                                             \
     if (h == HID && r == RR) {                                                                                          \
-        bottleneck_k<T, HID, RR, MODE><<<grid, block, 0, st>>>((u16*)Y, (u16*)Hout, (const u16*)X, (const u16*)Wa,       \
-                                                               (const u16*)ba, (const u16*)Wb, (const u16*)bb,          \
-                                                               (const u16*)Hsaved, rows);                               \
+        bottleneck_dma_k<T, HID, RR, MODE><<<grid, block, 0, st>>>((u16*)Y, (u16*)Hout, (const u16*)X, (const u16*)Wa,   \
+                                                                   (const u16*)ba, (const u16*)Wb, (const u16*)bb,      \
+                                                                   (const u16*)Hsaved, rows);                           \
         MM_CHECK_LAUNCH();                                                                                              \
         return MM_OK;                                                                                                   \
     }
