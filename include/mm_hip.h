@@ -179,6 +179,13 @@ int mm_gemm_tn_pair(void* C0, void* a_colsum0, const void* A0, const void* B0, i
 int mm_adapter_supported(int h, int r);
 int mm_adapter_fwd(void* out, void* h1, const void* o, const void* w1, const void* b1, const void* w2, const void* b2,
                    int rows, int h, int r, int dtype, void* stream);
+/* mm_adapter_fwd with the GPT-J residual tail of the layer on its output store (the MLP's adapter is the last kernel of a
+ * MAGMA layer): out = [residual +] ((attn + attn_bias) + (adapter(o) + mlp_bias)), every intermediate rounded to `dtype`
+ * as mm_gptj_combine does (megatron/model/transformer.py:747-766) - bit-identical to mm_adapter_fwd + mm_gptj_combine.
+ * residual may be NULL (TP > 1: the all-reduce sits between); h1 as in mm_adapter_fwd. */
+int mm_adapter_fwd_combine(void* out, void* h1, const void* o, const void* w1, const void* b1, const void* w2, const void* b2,
+                           const void* residual, const void* attn, const void* attn_bias, const void* mlp_bias, int rows,
+                           int h, int r, int dtype, void* stream);
 int mm_adapter_bwd_dx(void* dx, void* dpre, const void* dy, const void* w2, const void* w1, const void* h1, int rows,
                       int h, int r, int dtype, void* stream);
 

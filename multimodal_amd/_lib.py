@@ -46,6 +46,7 @@ PROTOTYPES = {
     "mm_gemm_tn_splits": (c_int, [c_int, c_int, c_int]),
     "mm_adapter_supported": (c_int, [c_int, c_int]),
     "mm_adapter_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
+    "mm_adapter_fwd_combine": (c_int, [c_void_p] * 11 + [c_int] * 4 + [c_void_p]),
     "mm_adapter_bwd_dx": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "mm_gemm_tn_pair_splits": (c_int, [c_int] * 5),
     "mm_gemm_tn_pair": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] + [c_int] * 2 + [c_void_p]),

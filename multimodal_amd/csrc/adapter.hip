@@ -78,45 +78,64 @@ __device__ __forceinline__ void ad_barrier() {
 }
 
 // VMEM operations a wave has issued AFTER the last DMA instruction of tile `tile`, counted at the end of step `step`
-// (step -1 = right after the prologue).  Issue order per wave: prologue tiles 0..PD; then in step s the DMA of tile
-// s+PD+1, then that step's global store (H tile in step S1, output chunk c-1 in step S1+c).  A tile = [one X-chunk
-// instruction if the wave is an X mover and the tile belongs to the first product] + NW weight instructions.
-constexpr int ad_younger(int tile, int step, int NW, int S1, int S, bool mover, bool hstore) {
+// (step -1 = right after the prologue); 63 ("no wait") when the wave issues no DMA for that tile.  The waves split roles so
+// that the in-order VMEM queue of the waves that confirm the weight tiles holds nothing slow: waves 0-3 ("movers") bring
+// the X chunks in (one DMA instruction per first-product tile), load the residual-tail operands (CMB) and store the output
+// chunks - HBM-latency traffic; waves 4-7 ("loaders") issue ALL weight DMAs (L2-resident, NWL instructions per tile) and
+// nothing else but their piece of the H-tile store.  Issue order per wave: prologue tiles 0..PD; then in step s the DMA
+// of tile s+PD+1, then (CMB movers, from step S1-2 on) operand loads of later chunks, then that step's global
+// store (H tile in step S1, output chunk c-1 in step S1+c: movers only).
+constexpr int ad_younger(int tile, int step, bool mover, int NWL, int S1, int S, bool hstore, bool cmb) {
+    auto ops_of = [&](int t) { return mover ? (t < S1 ? 1 : 0) : NWL; };
+    if (tile >= S || ops_of(tile) == 0) return 63;
     int count = -1;  // -1: the tile's DMA not seen yet
     auto emit_tile = [&](int t) {
-        const int ops = NW + ((mover && t < S1) ? 1 : 0);
-        if (count >= 0) count += ops;
+        if (count >= 0) count += ops_of(t);
         if (t == tile) count = 0;
     };
     for (int t = 0; t <= AD_PD; ++t)
         if (t < S) emit_tile(t);
     for (int s = 0; s <= step; ++s) {
         if (s + AD_PD + 1 < S) emit_tile(s + AD_PD + 1);
+        // (CMB: the movers' residual-tail operand loads start in step S1-2, after their last X-chunk wait (end of step S1-3),
+        //  and the movers confirm no tile after that: the loads never enter a counted wait)
         const bool st = (s == S1) ? hstore : (s > S1 ? mover : false);
         if (st && count >= 0) count += 1;
     }
-    return count < 0 ? 0 : count;
+    return count < 0 ? 0 : (count > 63 ? 63 : count);
 }
 
-template <typename T, int HID, int R, int MODE>  // MODE 0: forward, 1: backward (data gradient)
+// CMB (forward only): the GPT-J residual tail rides on the output store - Y = [res +] ((attn + attn_b) + (adapter(X) + mlp_b))
+// with the eager roundings of mm_gptj_combine (megatron/model/transformer.py:747-766 at hidden_dropout = 0).
+struct AdCombine {
+    const u16* res;     // [rows, HID] or nullptr
+    const u16* attn;    // [rows, HID]
+    const u16* attn_b;  // [HID]
+    const u16* mlp_b;   // [HID]
+};
+
+template <typename T, int HID, int R, int MODE, bool CMB>  // MODE 0: forward, 1: backward (data gradient)
 __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__ Y, u16* __restrict__ Hout, const u16* __restrict__ X,
                                                                const u16* __restrict__ Wa, const u16* __restrict__ ba,
                                                                const u16* __restrict__ Wb, const u16* __restrict__ bb,
-                                                               const u16* __restrict__ Hsaved, int rows) {
+                                                               const u16* __restrict__ Hsaved, int rows, AdCombine cmb) {
+    static_assert(!CMB || MODE == 0, "the residual tail is fused into the forward only");
+    static_assert(!CMB || (HID / 64 >= 5 && AD_PD == 3), "CMB operand schedule assumes >= 5 chunks and the last X wait in step S1-3");
     typedef typename Mfma<T>::frag frag;
     constexpr int HROW = R * 2, HCPR = R / 8;
     constexpr int HSW = HCPR >= 16 ? 15 : HCPR - 1;
     constexpr int NI1 = R / 64, S1 = HID / 64, S2 = HID / 64, S = S1 + S2, KS2 = R / 32;
     constexpr int RING = R * 128;              // bytes per tile: Wa tile [R][64] / [64][R], Wb chunk [64][R] / [R][64]
-    constexpr int NW = RING / 1024 / 8;        // DMA instructions per wave per tile
-    static_assert(RING % 8192 == 0 && NW >= 1, "a tile must be a whole number of DMA instructions per wave");
+    constexpr int NW = RING / 1024 / 4;        // weight DMA instructions per LOADER wave (waves 4-7) per tile
+    static_assert(RING % 4096 == 0 && NW >= 1, "a tile must be a whole number of DMA instructions per loader wave");
     constexpr int XS_BYTES = S1 * 4096, HS_BYTES = AD_BM * HROW;
     constexpr int T1SEG = HROW / 32;
-    constexpr bool HSTORE_ALL = (AD_BM * HCPR == AD_THREADS);  // does every wave store a piece of the H tile?
+    constexpr bool HSTORE_ALL = (AD_BM * HCPR == AD_THREADS);  // do the loader waves store a piece of the H tile too?
     static_assert(AD_BM * HCPR == AD_THREADS || AD_BM * HCPR == 256, "H tile store: all waves or exactly the X movers");
-    __shared__ __attribute__((aligned(1024))) char smem[XS_BYTES + HS_BYTES + AD_NB * RING + HID * 2];
+    __shared__ __attribute__((aligned(1024))) char smem[XS_BYTES + HS_BYTES + AD_NB * RING + HID * 2 * (CMB ? 3 : 1)];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
     const uint32_t XS = lds0, HS = lds0 + XS_BYTES, WS = HS + HS_BYTES, BS = WS + AD_NB * RING;
+    const uint32_t BSA = BS + HID * 2, BSM = BS + HID * 4;  // CMB: attention / MLP output biases
     const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fq = lane >> 4;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as a scalar: uniform branches, scalar LDS bases
     const int wave = w8 & 3, wmi = w8 >> 2;
@@ -140,6 +159,10 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__
         else small1[ni] = *reinterpret_cast<const u32x2*>(Hsaved + (size_t)min(m0 + mrow, rows - 1) * R + n0);
     }
     if (MODE == 0 && tid < HID / 8) bbreg = *reinterpret_cast<const u32x4*>(bb + tid * 8);
+    if (CMB && tid >= HID / 8 && tid < 3 * (HID / 8)) {
+        const int t2 = tid - HID / 8;
+        bbreg = (t2 < HID / 8) ? *reinterpret_cast<const u32x4*>(cmb.attn_b + t2 * 8) : *reinterpret_cast<const u32x4*>(cmb.mlp_b + (t2 - HID / 8) * 8);
+    }
 
     // ---- per-lane DMA sources.  Physical 16-byte slot P of a tile image holds logical piece (row, ch) with the swizzle of
     // the matching read formula below; instruction j of a tile fills slots 64j .. 64j+63.
@@ -147,7 +170,7 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__
     const u16* wb_src[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        const int j = w8 * NW + i;
+        const int j = (w8 & 3) * NW + i;  // (only the loader waves, w8 >= 4, use these)
         if (MODE == 0) {
             {   // Wa = W1 [R][HID]: tile s = columns 64s..: image [R rows][128 B], piece ^ ((row >> 1) & 7)
                 const int row = 8 * j + (lane >> 3), q = lane & 7;
@@ -180,30 +203,61 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__
                 if (xmover)
                     __builtin_amdgcn_global_load_lds((const void*)(x_src + t * 64), (lds_void*)(smem + t * 4096 + w8 * 1024), 16, 0, 0);
             }
-            char* buf = smem + XS_BYTES + HS_BYTES + (t % AD_NB) * RING + w8 * NW * 1024;
+            if (!xmover) {
+                char* buf = smem + XS_BYTES + HS_BYTES + (t % AD_NB) * RING + (w8 & 3) * NW * 1024;
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const u16* src;
-                if constexpr (t < S1) src = wa_src[i] + (size_t)t * WA_STRIDE;
-                else src = wb_src[i] + (size_t)(t - S1) * WB_STRIDE;
-                __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(buf + i * 1024), 16, 0, 0);
+                for (int i = 0; i < NW; ++i) {
+                    const u16* src;
+                    if constexpr (t < S1) src = wa_src[i] + (size_t)t * WA_STRIDE;
+                    else src = wb_src[i] + (size_t)(t - S1) * WB_STRIDE;
+                    __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(buf + i * 1024), 16, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the DMA block where the wait arithmetic (ad_younger) assumes it is
     };
     auto wait_tile = [&](auto tc, auto sc) {  // tile `t` landed (this wave's share), counted at the end of step `st`; + all LDS ops
         constexpr int t = decltype(tc)::value, st = decltype(sc)::value;
-        if constexpr (t < S) {
-            constexpr int ym = ad_younger(t, st, NW, S1, S, true, true), yo = ad_younger(t, st, NW, S1, S, false, HSTORE_ALL);
-            if (xmover) AD_WAIT(ym, 0);
-            else AD_WAIT(yo, 0);
-        } else {
-            AD_WAIT(63, 0);
-        }
+        constexpr int ym = ad_younger(t, st, true, NW, S1, S, true, CMB), yo = ad_younger(t, st, false, NW, S1, S, HSTORE_ALL, CMB);
+        if (xmover) AD_WAIT(ym, 0);
+        else AD_WAIT(yo, 0);
     };
 
     static_for<0, AD_PD + 1>([&](auto tc) { fill(tc); });
-    if (MODE == 0 && tid < HID / 8) ad_wr16(BS + tid * 16, bbreg);
+    if (MODE == 0 && tid < (CMB ? 3 : 1) * (HID / 8)) ad_wr16(BS + tid * 16, bbreg);  // [bb | attn_b | mlp_b], 2 KiB each
+    static_assert(3 * (HID / 8) <= AD_THREADS, "one 16-byte bias piece per thread");
+    // CMB: operands of the residual tail for output chunk k (this thread's piece), loaded two steps before they are used
+    u32x4 c_res[S2], c_att[S2];
+    const size_t c_off = (size_t)min(m0 + xrow, rows - 1) * HID + xpc * 8;
+    auto cmb_issue = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (CMB && k >= 0 && k < S2) {
+            if (xmover) {
+                c_att[k] = *reinterpret_cast<const u32x4*>(cmb.attn + c_off + k * 64);
+                c_res[k] = cmb.res ? *reinterpret_cast<const u32x4*>(cmb.res + c_off + k * 64) : u32x4{0u, 0u, 0u, 0u};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto cmb_apply = [&](auto kc, u32x4 yv, u32x4 bav, u32x4 bmv) {  // eager roundings of gptj_combine_k (elementwise.hip)
+        constexpr int k = decltype(kc)::value;
+        if constexpr (CMB) {
+            float a[8], at[8], xr[8], b1[8], b2[8], o[8];
+            unpack8<T>(yv, a);
+            unpack8<T>(c_att[k], at);
+            unpack8<T>(c_res[k], xr);
+            unpack8<T>(bav, b1);
+            unpack8<T>(bmv, b2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t3 = rnd<T>(rnd<T>(at[j] + b1[j]) + rnd<T>(a[j] + b2[j]));
+                o[j] = cmb.res ? xr[j] + t3 : t3;
+            }
+            return pack8<T>(o);
+        } else {
+            return yv;
+        }
+    };
 
     // transposed fragment of a [k][n] tile image (row bytes rb, nseg 32-byte segments per row): lane (i = lane&15, g = lane>>4)
     // gets tile[kb + 8g + j][n0 + i], j = 0..7 (lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3)
@@ -271,6 +325,10 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__
             for (int ni = 0; ni < NI1; ++ni)
                 acc1[ni] = Mfma<T>::run(__builtin_bit_cast(frag, FB[s][kk][ni]), __builtin_bit_cast(frag, FA[s][kk]), acc1[ni]);
         fill(std::integral_constant<int, s + AD_PD + 1>{});  // issued behind the MFMAs: the DMA issue slots overlap their execution
+        // CMB operand schedule (HBM latency is several steps): chunks 0-3 in step S1-2, chunk 4 in S1-1, then chunk c+5 in
+        // second-product step c; chunk k is consumed in second-product step k+1
+        if constexpr (s + 2 == S1) static_for<0, 4>([&](auto kc) { cmb_issue(kc); });
+        if constexpr (s + 1 == S1) cmb_issue(std::integral_constant<int, 4>{});
         if constexpr (s + 1 == S1) {  // the H tile: lane holds H[mrow][n0 .. n0+3], n0 = nb1 + ni*16 + fq*4
 #pragma unroll
             for (int ni = 0; ni < NI1; ++ni) {
@@ -304,8 +362,15 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__
             }
         }
         frags2(std::integral_constant<int, c + 1>{});
+        u32x4 ybav = u32x4{0u, 0u, 0u, 0u}, ybmv = u32x4{0u, 0u, 0u, 0u};
         if constexpr (c > 0) {
-            if (xmover) yv = ad_rd16(XS + (c - 1) * 4096 + xrow * 128 + ((xpc ^ ((xrow >> 1) & 7)) << 4));
+            if (xmover) {
+                yv = ad_rd16(XS + (c - 1) * 4096 + xrow * 128 + ((xpc ^ ((xrow >> 1) & 7)) << 4));
+                if (CMB) {
+                    ybav = ad_rd16(BSA + ((c - 1) * 64 + xpc * 8) * 2);
+                    ybmv = ad_rd16(BSM + ((c - 1) * 64 + xpc * 8) * 2);
+                }
+            }
         }
         const int n0 = c * 64 + wave * 16 + fq * 4;
         const uint32_t xaddr = XS + c * 4096 + mrow * 128 + (((wave * 2 + (fq >> 1)) ^ ((mrow >> 1) & 7)) << 4) + (fq & 1) * 8;
@@ -318,6 +383,7 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__
         for (int ks = 0; ks < KS2; ++ks)
             acc2 = Mfma<T>::run(__builtin_bit_cast(frag, FB2[c][ks]), __builtin_bit_cast(frag, fh[ks]), acc2);
         fill(std::integral_constant<int, s + AD_PD + 1>{});
+        cmb_issue(std::integral_constant<int, c + 5>{});
         AD_WAIT(63, 0);  // xv, bvr, yv, hv, the next chunk's fragments
         if constexpr (c == 0) {
             if (tid < AD_BM * HCPR) {
@@ -325,7 +391,9 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__
                 if (m0 + row < rows) *reinterpret_cast<u32x4*>(Hout + (size_t)(m0 + row) * R + ch * 8) = hv;
             }
         } else {
-            if (xmover && m0 + xrow < rows) *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + xrow) * HID + (c - 1) * 64 + xpc * 8) = yv;
+            if (xmover && m0 + xrow < rows)
+                *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + xrow) * HID + (c - 1) * 64 + xpc * 8) =
+                    cmb_apply(std::integral_constant<int, c - 1>{}, yv, ybav, ybmv);
         }
         __builtin_amdgcn_sched_barrier(0);
         float bv[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
@@ -340,8 +408,15 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__
     });
     if (xmover) {
         const u32x4 yv = ad_rd16(XS + (S2 - 1) * 4096 + xrow * 128 + ((xpc ^ ((xrow >> 1) & 7)) << 4));
+        u32x4 ybav = u32x4{0u, 0u, 0u, 0u}, ybmv = u32x4{0u, 0u, 0u, 0u};
+        if (CMB) {
+            ybav = ad_rd16(BSA + ((S2 - 1) * 64 + xpc * 8) * 2);
+            ybmv = ad_rd16(BSM + ((S2 - 1) * 64 + xpc * 8) * 2);
+        }
         AD_WAIT(63, 0);
-        if (m0 + xrow < rows) *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + xrow) * HID + (S2 - 1) * 64 + xpc * 8) = yv;
+        if (m0 + xrow < rows)
+            *reinterpret_cast<u32x4*>(Y + (size_t)(m0 + xrow) * HID + (S2 - 1) * 64 + xpc * 8) =
+                cmb_apply(std::integral_constant<int, S2 - 1>{}, yv, ybav, ybmv);
     }
 #ifdef MM_AD_STAMP
     {
@@ -355,15 +430,15 @@ __global__ __launch_bounds__(AD_THREADS) void bottleneck_dma_k(u16* __restrict__
 #endif
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool CMB = false>
 static int launch_bottleneck(void* Y, void* Hout, const void* X, const void* Wa, const void* ba, const void* Wb, const void* bb,
-                             const void* Hsaved, int rows, int h, int r, hipStream_t st) {
+                             const void* Hsaved, int rows, int h, int r, hipStream_t st, AdCombine cmb = AdCombine{}) {
     dim3 grid((rows + AD_BM - 1) / AD_BM), block(AD_THREADS);
 #define MM_AD_CASE(HID, RR)                                                                                             \
     if (h == HID && r == RR) {                                                                                          \
-        bottleneck_dma_k<T, HID, RR, MODE><<<grid, block, 0, st>>>((u16*)Y, (u16*)Hout, (const u16*)X, (const u16*)Wa,   \
-                                                                   (const u16*)ba, (const u16*)Wb, (const u16*)bb,      \
-                                                                   (const u16*)Hsaved, rows);                           \
+        bottleneck_dma_k<T, HID, RR, MODE, CMB><<<grid, block, 0, st>>>((u16*)Y, (u16*)Hout, (const u16*)X,             \
+                                                                        (const u16*)Wa, (const u16*)ba, (const u16*)Wb, \
+                                                                        (const u16*)bb, (const u16*)Hsaved, rows, cmb); \
         MM_CHECK_LAUNCH();                                                                                              \
         return MM_OK;                                                                                                   \
     }
@@ -409,5 +484,20 @@ extern "C" int mm_adapter_bwd_dx(void* dx, void* dpre, const void* dy, const voi
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
         return launch_bottleneck<T, 1>(dx, dpre, dy, w2, nullptr, w1, nullptr, h1, rows, h, r, (hipStream_t)stream);
+    });
+}
+
+extern "C" int mm_adapter_fwd_combine(void* out, void* h1, const void* o, const void* w1, const void* b1, const void* w2, const void* b2,
+                                      const void* residual, const void* attn, const void* attn_bias, const void* mlp_bias, int rows,
+                                      int h, int r, int dtype, void* stream) {
+    MM_CHECK_ARG(out && h1 && o && w1 && b1 && w2 && b2 && attn && attn_bias && mlp_bias, "mm_adapter_fwd_combine: null pointer");
+    if (int rc = check_adapter("mm_adapter_fwd_combine", rows, h, r)) return rc;
+    MM_CHECK_ARG(aligned16(out) && aligned16(h1) && aligned16(o) && aligned16(w1) && aligned16(w2) && aligned16(b1) && aligned16(b2) &&
+                     aligned16(attn) && aligned16(attn_bias) && aligned16(mlp_bias) && (!residual || aligned16(residual)),
+                 "mm_adapter_fwd_combine: pointers must be 16-byte aligned");
+    const AdCombine cmb{(const u16*)residual, (const u16*)attn, (const u16*)attn_bias, (const u16*)mlp_bias};
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        return launch_bottleneck<T, 0, true>(out, h1, o, w1, b1, w2, b2, nullptr, rows, h, r, (hipStream_t)stream, cmb);
     });
 }

@@ -172,6 +172,38 @@ def adapter(o, w1, b1, w2, b2):
     return AdapterFn.apply(o, w1, b1, w2, b2)
 
 
+class AdapterCombineFn(torch.autograd.Function):
+    """out = [x +] ((attn + b_a) + (adapter(o) + b_m)): the MLP's adapter (the last kernel of a MAGMA layer) with the GPT-J
+    residual tail (GptjCombineFn) on its output store.  Backward = AdapterFn.backward on g, and g itself for x and attn."""
+
+    @staticmethod
+    def forward(ctx, o, w1, b1, w2, b2, x, attn, ba, bm):
+        out, h1 = ops.adapter_fwd_combine(o, w1, b1, w2, b2, x, attn, ba, bm)
+        ctx.save_for_backward(o, w1, w2, h1)
+        ctx.has_x = x is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        o, w1, w2, h1 = ctx.saved_tensors
+        g = g.contiguous()
+        g2 = _flat2d(g)
+        do, dpre = ops.adapter_bwd_dx(g2, w2.detach(), w1.detach(), _flat2d(h1))
+        do = do.view(o.shape)
+        if all(ctx.needs_input_grad[1:5]):
+            dw1, db1, dw2, db2 = ops.gemm_tn_pair(dpre, _flat2d(o), g2, _flat2d(h1))
+        else:
+            dw1, db1 = _wgrad_bias(dpre, _flat2d(o), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+            dw2, db2 = _wgrad_bias(g2, _flat2d(h1), ctx.needs_input_grad[3], ctx.needs_input_grad[4])
+        db = ops.colsum(g2) if (ctx.needs_input_grad[7] or ctx.needs_input_grad[8]) else None
+        return (do, dw1, db1, dw2, db2, (g if ctx.has_x else None), g, (db if ctx.needs_input_grad[7] else None),
+                (db if ctx.needs_input_grad[8] else None))
+
+
+def adapter_combine(o, w1, b1, w2, b2, x, attn, attn_bias, mlp_bias):
+    return AdapterCombineFn.apply(o, w1, b1, w2, b2, x, attn, attn_bias, mlp_bias)
+
+
 class LayerNormFn(torch.autograd.Function):
     """torch.nn.LayerNorm of the layer (megatron/model/norms.py:16-31)."""
 

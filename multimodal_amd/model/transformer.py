@@ -168,6 +168,19 @@ class ParallelTransformerLayer(nn.Module):
         # module dtype follows the engine's cast (`layer.to(dtype)`), like the reference's LayerNorm / inv_freq
         self.to(neox_args.params_dtype)
 
+    def _fused_adapter_tail(self):
+        """(adapter Linear 0, Linear 2) when `.mlp` is an AdapterWrapper of a shape the fused adapter kernel takes
+        (training.py:421-432 wraps `.mlp` / `.attention`), else None."""
+        from .adapter import AdapterWrapper
+        from .. import ops
+        m = self.mlp
+        if type(m) is not AdapterWrapper:
+            return None
+        a0, a2 = m.adapter[0], m.adapter[2]
+        if not ops.adapter_supported(a0.weight.size(1), a0.weight.size(0)):
+            return None
+        return a0, a2
+
     def _get_bias_dropout(self):
         if self.bias_dropout_fusion:
             return bias_dropout_add_fused_train if self.training else bias_dropout_add_fused_inference
@@ -187,8 +200,19 @@ class ParallelTransformerLayer(nn.Module):
             else:
                 x1, x2 = ln1(x), ln2(x)
             attention_output, attention_bias = self.attention(x1, attention_mask, layer_past=layer_past)
-            mlp_output, mlp_bias = self.mlp(x2)
             no_drop = self.hidden_dropout == 0 or not self.training
+            tail = self._fused_adapter_tail() if no_drop else None
+            if tail is not None:
+                # MAGMA layer: the MLP's adapter is the last kernel, so the residual tail rides on its output store
+                a0, a2 = tail
+                mlp_raw, mlp_bias = self.mlp.attn_block(x2)
+                tp1 = mpu.get_model_parallel_world_size() == 1
+                output = Fn.adapter_combine(mlp_raw, a0.weight, a0.bias, a2.weight, a2.bias, residual if tp1 else None,
+                                            attention_output, attention_bias, mlp_bias)
+                if tp1:
+                    return output
+                return Fn.bias_dropout_add(self.reduce(output), None, residual, 0.0, False)
+            mlp_output, mlp_bias = self.mlp(x2)
             if no_drop:
                 # bias_dropout_add x2 (+ the residual add when TP == 1) in one pass
                 if mpu.get_model_parallel_world_size() == 1:

@@ -368,6 +368,25 @@ def adapter_fwd(o, w1, b1, w2, b2):
     return out.view(o.shape), h1
 
 
+def adapter_fwd_combine(o, w1, b1, w2, b2, residual, attn, attn_bias, mlp_bias):
+    """[residual +] ((attn + attn_bias) + (adapter(o) + mlp_bias)) - the adapter forward with the GPT-J residual tail on its
+    output store; returns (out, h1).  Bit-identical to adapter_fwd + gptj_combine."""
+    _need_cuda(o, w1, b1, w2, b2, residual, attn, attn_bias, mlp_bias)
+    h, r = w1.size(1), w1.size(0)
+    o2 = o.contiguous().view(-1, h)
+    attn2 = attn.contiguous().view(-1, h)
+    res2 = residual.contiguous().view(-1, h) if residual is not None else None
+    if attn2.shape != o2.shape or (res2 is not None and res2.shape != o2.shape) or attn_bias.numel() != h or mlp_bias.numel() != h:
+        raise RuntimeError("adapter_fwd_combine: shape mismatch")
+    out = torch.empty_like(o2)
+    h1 = torch.empty(o2.size(0), r, dtype=o.dtype, device=o.device)
+    check(get_lib().mm_adapter_fwd_combine(out.data_ptr(), h1.data_ptr(), o2.data_ptr(), w1.contiguous().data_ptr(), b1.data_ptr(),
+                                           w2.contiguous().data_ptr(), b2.data_ptr(), _ptr(res2), attn2.data_ptr(),
+                                           attn_bias.contiguous().data_ptr(), mlp_bias.contiguous().data_ptr(), o2.size(0), h, r,
+                                           dtype_code(o.dtype), _stream()), "adapter_fwd_combine")
+    return out.view(o.shape), h1
+
+
 def adapter_bwd_dx(dy, w2, w1, h1):
     """(dx, dpre) of the adapter: dpre = (dy W2) * (h1 > 0), dx = dy + dpre W1; W2 [h, r] and W1 [r, h] as stored."""
     _need_cuda(dy, w2, w1, h1)

@@ -586,3 +586,23 @@ def test_gemm_qkv_rotary_rejects_unfused_shapes(ops, cuda_device):
     assert not ops.qkv_rotary_supported(128, 128, w.size(0), 64, 16, 2)
     with pytest.raises(RuntimeError, match="not a fused shape"):
         ops.gemm_nt_qkv_rotary(x, w, bias, cos, sin, 2, 128, 128)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("rows,h,r,with_res", [(8192, 1024, 128, True), (100, 1024, 128, False), (1000, 512, 64, True), (32, 512, 64, False)])
+def test_adapter_fwd_combine_equals_two_kernels(ops, cuda_device, dt, rows, h, r, with_res):
+    """mm_adapter_fwd_combine (GPT-J residual tail on the adapter's output store) is bit-identical to mm_adapter_fwd followed
+    by mm_gptj_combine, and saves the same h1."""
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dt]
+    torch.manual_seed(rows + h)
+    mk = lambda *s, sc=1.0: (torch.randn(*s) * sc).to(dtype).to(cuda_device)
+    o, x, attn = mk(rows, h), mk(rows, h), mk(rows, h)
+    w1, b1, w2, b2 = mk(r, h, sc=0.03), mk(r, sc=0.1), mk(h, r, sc=0.1), mk(h, sc=0.1)
+    ba, bm = mk(h, sc=0.2), mk(h, sc=0.2)
+    res = x if with_res else None
+    fused, h1f = ops.adapter_fwd_combine(o, w1, b1, w2, b2, res, attn, ba, bm)
+    mid, h1 = ops.adapter_fwd(o, w1, b1, w2, b2)
+    two = ops.gptj_combine(res, attn, ba, mid, bm)
+    torch.cuda.synchronize()
+    assert torch.equal(h1f.view(torch.int16), h1.view(torch.int16))
+    assert torch.equal(fused.view(torch.int16), two.view(torch.int16))
