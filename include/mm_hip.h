@@ -225,6 +225,15 @@ int mm_cross_entropy_fwd(float* loss, float* lse, const void* logits, const int6
 int mm_cross_entropy_bwd(void* dlogits, const void* logits, const int64_t* labels, const float* lse,
                          const float* row_scale, int T, int V, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ embedding + image prefix
+ * The step in front of the first layer in one pass: word-embedding gather, `cat((image_prefix, text[:, :s-P]), dim=1)` and
+ * the [b, s, h] -> [s, b, h] transpose (megatron/model/word_embeddings.py:135-205, gpt2_model.py:73-77):
+ *   out[si, bi, :] = si < P ? prefix[bi, si, :] : table[tokens[bi, si - P], :]
+ * out [s, b, h], table [V, h], prefix [b, P, h] (NULL when P == 0) - 2-byte elements of any 16-bit dtype (pure copy);
+ * tokens [b, s] int64 (ids clamped to [0, V)). */
+int mm_embed_prefix(void* out, const void* table, const int64_t* tokens, const void* prefix, int s, int b, int h, int P,
+                    int V, void* stream);
+
 /* ------------------------------------------------------------------ optimizer step (part of the timed step)
  * Mixed-precision Adam with global-norm gradient clipping over a list of 16-bit tensors, two launches per step.  States
  * the update rule of the optimizer the recipe constructs (apex / DeepSpeed FusedAdam in adam_w_mode under DeepSpeed's

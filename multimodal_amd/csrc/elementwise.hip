@@ -419,3 +419,45 @@ extern "C" int mm_gptj_combine(void* out, const void* x, const void* attn, const
         return (int)MM_OK;
     });
 }
+
+// ------------------------------------------------------------------------------------ embedding + image prefix
+// out[si, bi, :] = si < P ? prefix[bi, si, :] : table[tokens[bi, si - P], :]
+// = word embedding gather + `cat((image_prefix, text[:, :s-P]), dim=1)` + the [b, s, h] -> [s, b, h] transpose in front of
+// the first layer (megatron/model/word_embeddings.py:135-205, gpt2_model.py:73-77) in one pass: 16 bytes per lane, each
+// output row written once.  Token ids are clamped to [0, V) (the reference would fault on an id outside the table).
+namespace mm {
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256) void embed_prefix_k(u16* __restrict__ out, const u16* __restrict__ table,
+                                                      const long long* __restrict__ tokens, const u16* __restrict__ prefix, int s,
+                                                      int b, int h, int P, int V) {
+    const int cpr = h >> 3;  // 16-byte chunks per row
+    const size_t total = (size_t)s * b * cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr);
+        const size_t row = i / cpr;  // = si * b + bi
+        const int si = (int)(row / b), bi = (int)(row % b);
+        const u16* src;
+        if (si < P) {
+            src = prefix + ((size_t)bi * P + si) * h;
+        } else {
+            long long t = tokens[(size_t)bi * s + (si - P)];
+            t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+            src = table + (size_t)t * h;
+        }
+        *reinterpret_cast<u32x4*>(out + row * h + c * 8) = *reinterpret_cast<const u32x4*>(src + c * 8);
+    }
+}
+}  // namespace mm
+
+extern "C" int mm_embed_prefix(void* out, const void* table, const int64_t* tokens, const void* prefix, int s, int b, int h, int P,
+                               int V, void* stream) {
+    MM_CHECK_ARG(out && table && tokens, "mm_embed_prefix: null pointer");
+    MM_CHECK_ARG(s > 0 && b > 0 && h > 0 && V > 0 && h % 8 == 0, "mm_embed_prefix: s=%d b=%d h=%d V=%d (h must be a multiple of 8)", s, b, h, V);
+    MM_CHECK_ARG(P >= 0 && P <= s && (P == 0 || prefix != nullptr), "mm_embed_prefix: prefix length %d out of range (s=%d) or prefix missing", P, s);
+    MM_CHECK_ARG(aligned16(out) && aligned16(table) && (!prefix || aligned16(prefix)), "mm_embed_prefix: pointers must be 16-byte aligned");
+    const size_t items = (size_t)s * b * (h / 8);
+    mm::embed_prefix_k<><<<mm::grid_for(items), 256, 0, (hipStream_t)stream>>>((u16*)out, (const u16*)table, (const long long*)tokens,
+                                                                              (const u16*)prefix, s, b, h, P, V);
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}

@@ -83,20 +83,27 @@ __global__ __launch_bounds__(256) void gemm_tn_k(TnProb p0, TnProb p1, float* __
         for (int e = 0; e < 16; ++e) cs[i][e] = 0.f;
     const frag ones = Ones<T>::get();
 
-    u32x4 areg[4], breg[4];
-    tn_tile_load(areg, A, lda, m_begin, n0, tid);
-    tn_tile_load(breg, B, ldb, m_begin, k0, tid);
-    tile_store<128>(smem, areg, tid);
-    tile_store<128>(smem + TL::BYTES, breg, tid);
+    // Tiles come from HBM (dY, X: 16 MiB each) and a 64-token step is only 16 MFMAs per wave, so the loop is bound by how many
+    // bytes are in flight: TWO tiles are prefetched in registers (64 KiB per workgroup) beyond the one being multiplied.
+    // Register set (t & 1) holds tile t from its load until it is written to LDS buffer (t & 1) at the end of iteration t-1.
+    u32x4 areg[2][4], breg[2][4];
+    tn_tile_load(areg[0], A, lda, m_begin, n0, tid);
+    tn_tile_load(breg[0], B, ldb, m_begin, k0, tid);
+    if (ntile > 1) {
+        tn_tile_load(areg[1], A, lda, m_begin + 64, n0, tid);
+        tn_tile_load(breg[1], B, ldb, m_begin + 64, k0, tid);
+    }
+    tile_store<128>(smem, areg[0], tid);
+    tile_store<128>(smem + TL::BYTES, breg[0], tid);
     __syncthreads();
 
-    for (int t = 0; t < ntile; ++t) {
-        const int cur = t & 1;
+    auto body = [&](int t, auto parity) {
+        constexpr int cur = decltype(parity)::value;  // == t & 1
         const char* as = smem + cur * 2 * TL::BYTES;
         const char* bs = as + TL::BYTES;
-        if (t + 1 < ntile) {
-            tn_tile_load(areg, A, lda, m_begin + (t + 1) * 64, n0, tid);
-            tn_tile_load(breg, B, ldb, m_begin + (t + 1) * 64, k0, tid);
+        if (t + 2 < ntile) {  // set `cur` is free: tile t went to LDS at the end of the previous iteration
+            tn_tile_load(areg[cur], A, lda, m_begin + (t + 2) * 64, n0, tid);
+            tn_tile_load(breg[cur], B, ldb, m_begin + (t + 2) * 64, k0, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -117,10 +124,14 @@ __global__ __launch_bounds__(256) void gemm_tn_k(TnProb p0, TnProb p1, float* __
         }
         if (t + 1 < ntile) {
             char* nx = smem + (cur ^ 1) * 2 * TL::BYTES;
-            tile_store<128>(nx, areg, tid);
-            tile_store<128>(nx + TL::BYTES, breg, tid);
+            tile_store<128>(nx, areg[cur ^ 1], tid);
+            tile_store<128>(nx + TL::BYTES, breg[cur ^ 1], tid);
         }
         __syncthreads();
+    };
+    for (int t = 0; t < ntile; t += 2) {
+        body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ntile) body(t + 1, std::integral_constant<int, 1>{});
     }
     // D[row = n (registers)][col = kp (lane)]
     float* wsp = ws + (size_t)blockIdx.y * slab + P.ws_off;

@@ -426,3 +426,30 @@ def masked_cross_entropy(logits, labels, loss_mask):
     losses = CrossEntropyFn.apply(logits.reshape(-1, V), labels.reshape(-1).contiguous())
     lm = loss_mask.reshape(-1).float()
     return torch.sum(losses * lm) / lm.sum()
+
+
+class EmbedPrefixFn(torch.autograd.Function):
+    """Word embeddings + image-prefix concat + transpose to [s, b, h] (megatron/model/word_embeddings.py:135-205,
+    gpt2_model.py:73-77) for a FROZEN embedding table: only the prefix rows carry a gradient back."""
+
+    @staticmethod
+    def forward(ctx, prefix, table, tokens):
+        ctx.P = 0 if prefix is None else prefix.size(1)
+        return ops.embed_prefix(table.detach(), tokens, None if prefix is None else prefix.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        dprefix = None
+        if ctx.P > 0 and ctx.needs_input_grad[0]:
+            dprefix = g[:ctx.P].transpose(0, 1).contiguous()  # [b, P, h]: P rows of the gradient
+        return dprefix, None, None
+
+
+def embed_prefix(prefix, table, tokens):
+    """First-layer input [s, b, h].  A trainable table takes the unfused path (its gradient is a scatter-add)."""
+    if table.requires_grad:
+        emb = torch.nn.functional.embedding(tokens, table)
+        if prefix is not None:
+            emb = torch.cat((prefix, emb[:, : tokens.size(1) - prefix.size(1), :]), dim=1)
+        return emb.transpose(0, 1).contiguous()
+    return EmbedPrefixFn.apply(prefix, table, tokens)

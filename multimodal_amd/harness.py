@@ -121,11 +121,9 @@ class MagmaStack(nn.Module):
     def forward(self, enc_out, tokens, labels, loss_mask):
         """enc_out [b, P, enc_dim] | None, tokens [b, s] int64, labels [b, s], loss_mask [b, s] float -> scalar loss."""
         b, s = tokens.shape
-        emb = self.word_embeddings(tokens)  # gather: plumbing (SURVEY 8f3 is the fused form)
-        if self.image_prefix is not None:
-            pre = self.image_prefix(enc_out)
-            emb = torch.cat((pre, emb[:, : s - pre.size(1), :]), dim=1)
-        x = emb.transpose(0, 1).contiguous()  # [s, b, h]
+        pre = self.image_prefix(enc_out) if self.image_prefix is not None else None
+        # gather + [prefix | text[:, :s-P]] + [b,s,h] -> [s,b,h] in one kernel (SURVEY 8 f3)
+        x = Fn.embed_prefix(pre, self.word_embeddings.weight, tokens)
         mask = self.attention_mask(s, x.device)
         for layer in self.layers:
             x = layer(x, mask)

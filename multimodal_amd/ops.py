@@ -466,3 +466,24 @@ def cross_entropy_bwd(logits, labels, lse, row_scale, out=None):
     check(get_lib().mm_cross_entropy_bwd(out.data_ptr(), logits.data_ptr(), labels.data_ptr(), lse.data_ptr(),
                                          row_scale.data_ptr(), T, V, dtype_code(logits.dtype), _stream()), "cross_entropy_bwd")
     return out
+
+
+# ---------------------------------------------------------------------------- embedding + image prefix
+def embed_prefix(table, tokens, prefix=None):
+    """[s, b, h] input of the first layer: out[si, bi] = prefix[bi, si] for si < P else table[tokens[bi, si - P]]
+    (word-embedding gather + image-prefix concat + [b,s,h]->[s,b,h] transpose in one kernel)."""
+    _need_cuda(table, tokens, prefix)
+    if table.dim() != 2 or table.element_size() != 2 or tokens.dim() != 2 or tokens.dtype != torch.int64:
+        raise RuntimeError("embed_prefix: table must be a 16-bit [V, h] tensor and tokens an int64 [b, s] tensor")
+    b, s = tokens.shape
+    V, h = table.shape
+    P = 0
+    if prefix is not None:
+        if prefix.dim() != 3 or prefix.size(0) != b or prefix.size(2) != h or prefix.dtype != table.dtype:
+            raise RuntimeError("embed_prefix: prefix must be [b, P, h] in the table's dtype")
+        P = prefix.size(1)
+        prefix = prefix.contiguous()
+    out = torch.empty(s, b, h, dtype=table.dtype, device=table.device)
+    check(get_lib().mm_embed_prefix(out.data_ptr(), table.contiguous().data_ptr(), tokens.contiguous().data_ptr(), _ptr(prefix),
+                                    s, b, h, P, V, _stream()), "embed_prefix")
+    return out

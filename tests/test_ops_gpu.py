@@ -606,3 +606,24 @@ def test_adapter_fwd_combine_equals_two_kernels(ops, cuda_device, dt, rows, h, r
     torch.cuda.synchronize()
     assert torch.equal(h1f.view(torch.int16), h1.view(torch.int16))
     assert torch.equal(fused.view(torch.int16), two.view(torch.int16))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("b,s,h,P,V", [(2, 16, 64, 1, 100), (3, 33, 128, 5, 1000), (4, 2048, 1024, 1, 50304), (2, 8, 64, 0, 50)])
+def test_embed_prefix_equals_gather_cat_transpose(ops, cuda_device, dt, b, s, h, P, V):
+    """mm_embed_prefix == embedding gather + cat((prefix, text[:, :s-P]), 1) + transpose(0, 1) (word_embeddings.py:197-203,
+    gpt2_model.py:73-77), bit for bit (a pure copy), and its autograd node returns the prefix rows' gradient."""
+    from multimodal_amd import functional as Fn
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dt]
+    torch.manual_seed(s)
+    table = torch.randn(V, h).to(dtype).to(cuda_device)
+    tokens = torch.randint(0, V, (b, s)).to(cuda_device)
+    prefix = torch.randn(b, P, h).to(dtype).to(cuda_device).requires_grad_(True) if P > 0 else None
+    out = Fn.embed_prefix(prefix, table, tokens)
+    emb = torch.nn.functional.embedding(tokens, table)
+    ref = (torch.cat((prefix.detach(), emb[:, : s - P, :]), dim=1) if P > 0 else emb).transpose(0, 1).contiguous()
+    assert out.shape == (s, b, h) and torch.equal(out, ref)
+    if P > 0:
+        g = torch.randn(s, b, h).to(dtype).to(cuda_device)
+        out.backward(g)
+        assert torch.equal(prefix.grad, g[:P].transpose(0, 1))
