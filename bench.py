@@ -251,13 +251,16 @@ def main():
     if rank == 0:
         roof = roofline_from_probe(cfg, probe)
         out = {
-            "metric": "train tokens/sec (node) magma_pythia_410M", "value": round(value, 1), "unit": "tokens/s",
+            "metric": "train tokens/sec (node) %s" % a.config, "value": round(value, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s image-prefix training step (configs[1]): L=%d h=%d heads=%d s=%d micro_batch=%d/GPU, "
-                                   "1 prefix token + text, adapters r=h/%d trainable, LM frozen, bf16, no activation recompute"
-                                   % (a.config, cfg["num_layers"], cfg["hidden_size"], cfg["num_attention_heads"],
-                                      cfg["seq_length"], cfg["micro_batch"], cfg["adapter_downsample_factor"]),
+            "config": {"workload": "%s training step%s: L=%d h=%d heads=%d s=%d micro_batch=%d/GPU, %s, %s, bf16, no activation recompute"
+                                   % (a.config, " (BASELINE.json configs[1])" if a.config == "magma_pythia_410M" else "",
+                                      cfg["num_layers"], cfg["hidden_size"], cfg["num_attention_heads"], cfg["seq_length"],
+                                      cfg["micro_batch"],
+                                      ("%d image-prefix token + text" % cfg["prefix_len"]) if cfg["prefix_len"] else "text only",
+                                      ("adapters r=h/%d trainable, LM frozen" % cfg["adapter_downsample_factor"])
+                                      if (cfg["add_adapters"] and cfg["freeze_lm"]) else "all parameters trainable"),
                        "global_batch": cfg["micro_batch"] * world, "seq_len": cfg["seq_length"], "parallelism": "dp%d" % world},
             "mfma_util_model": round(mfma_util, 4),
             "model_tflops_per_gpu": round(flops_step * a.steps / dt / 1e12, 1),

@@ -22,9 +22,10 @@ __global__ __launch_bounds__(256) void ce_fwd_k(float* __restrict__ loss, float*
     const size_t row = blockIdx.x;
     const u16* x = logits + row * (size_t)V;
     float m = -INFINITY, l = 0.f;
-    for (int c = threadIdx.x; c < (V >> 3); c += 256) {
+    const int nch = V >> 3;
+    auto fold = [&](const u32x4& raw) {
         float v[8];
-        unpack8<T>(*reinterpret_cast<const u32x4*>(x + c * 8), v);
+        unpack8<T>(raw, v);
         float cm = v[0];
 #pragma unroll
         for (int j = 1; j < 8; ++j) cm = fmaxf(cm, v[j]);
@@ -34,7 +35,20 @@ __global__ __launch_bounds__(256) void ce_fwd_k(float* __restrict__ loss, float*
         for (int j = 0; j < 8; ++j) acc += __expf(v[j] - mn);
         l = l * __expf(m - mn) + acc;
         m = mn;
+    };
+    // four 16-byte loads in flight per lane (a 100 KB row per block: the loop is bound by bytes in flight, not by the exps)
+    int c = threadIdx.x;
+    for (; c + 3 * 256 < nch; c += 4 * 256) {
+        const u32x4 r0 = *reinterpret_cast<const u32x4*>(x + (size_t)c * 8);
+        const u32x4 r1 = *reinterpret_cast<const u32x4*>(x + (size_t)(c + 256) * 8);
+        const u32x4 r2 = *reinterpret_cast<const u32x4*>(x + (size_t)(c + 512) * 8);
+        const u32x4 r3 = *reinterpret_cast<const u32x4*>(x + (size_t)(c + 768) * 8);
+        fold(r0);
+        fold(r1);
+        fold(r2);
+        fold(r3);
     }
+    for (; c < nch; c += 256) fold(*reinterpret_cast<const u32x4*>(x + (size_t)c * 8));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
