@@ -23,6 +23,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(u16* __restrict__ y, u16*
     const u16* xr = x + (size_t)row * h;
     float v[ITERS][8];
     float sum = 0.f;
+    // the affine parameters are requested together with the row (their latency hides behind the two reductions)
+    u32x4 wr[ITERS], br[ITERS], wr2[ITERS], br2[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = it * 64 + lane;
+        if (c < nchunk) {
+            wr[it] = *reinterpret_cast<const u32x4*>(w + c * 8);
+            br[it] = *reinterpret_cast<const u32x4*>(b + c * 8);
+            if (DUAL) {
+                wr2[it] = *reinterpret_cast<const u32x4*>(w2 + c * 8);
+                br2[it] = *reinterpret_cast<const u32x4*>(b2 + c * 8);
+            }
+        }
+    }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = it * 64 + lane;
@@ -61,14 +75,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(u16* __restrict__ y, u16*
         const int c = it * 64 + lane;
         if (c < nchunk) {
             float wv[8], bv[8], o[8];
-            unpack8<T>(*reinterpret_cast<const u32x4*>(w + c * 8), wv);
-            unpack8<T>(*reinterpret_cast<const u32x4*>(b + c * 8), bv);
+            unpack8<T>(wr[it], wv);
+            unpack8<T>(br[it], bv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (v[it][j] - mean) * rstd * wv[j] + bv[j];
             *reinterpret_cast<u32x4*>(y + (size_t)row * h + c * 8) = pack8<T>(o);
             if (DUAL) {
-                unpack8<T>(*reinterpret_cast<const u32x4*>(w2 + c * 8), wv);
-                unpack8<T>(*reinterpret_cast<const u32x4*>(b2 + c * 8), bv);
+                unpack8<T>(wr2[it], wv);
+                unpack8<T>(br2[it], bv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (v[it][j] - mean) * rstd * wv[j] + bv[j];
                 *reinterpret_cast<u32x4*>(y2 + (size_t)row * h + c * 8) = pack8<T>(o);
