@@ -40,11 +40,12 @@ def allreduce_gradients(params, group=None, bucket_bytes=256 << 20, average=True
                 flat.copy_(host)
             else:
                 torch.distributed.all_reduce(flat, group=group)
-            off = 0
+            views, off = [], 0
             for g in bucket:
                 n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
+                views.append(flat[off:off + n].view_as(g))
                 off += n
+            torch._foreach_copy_(bucket, views)  # one multi-tensor launch instead of one copy per gradient (~200 at 410M)
 
         for g in gs:
             if bucket and (size + g.numel()) * esz > bucket_bytes:
