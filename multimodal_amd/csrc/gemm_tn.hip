@@ -160,24 +160,39 @@ __global__ __launch_bounds__(256) void gemm_tn_k(TnProb p0, TnProb p1, float* __
     }
 }
 
-// out = sum_s ws[s][.] (fixed order), 4 elements per thread; a slab is [p0: N*Kp, N column sums | p1: the same]
+// out = sum_s ws[s][.] (fixed order: k ascending), 2 elements per thread (twice the waves of a 4-element version: the
+// slab pair is only ~1 MiB wide, so the kernel lives on loads in flight); a slab is [p0: N*Kp, N column sums | p1: the same]
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_k(TnProb p0, TnProb p1, const float* __restrict__ ws, size_t slab, int splits) {
-    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= slab) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(ws + i4);
-    for (int k = 1; k < splits; ++k) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)k * slab + i4);
-        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    const size_t i2 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i2 >= slab) return;
+    const float* w = ws + i2;
+    auto ld = [&](int k) { return *reinterpret_cast<const f32x2*>(w + (size_t)k * slab); };
+    f32x2 s = ld(0);
+    int k = 1;
+    if (splits >= 8) {  // eight independent loads in flight, then the adds in order
+        f32x2 v[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) v[u] = ld(1 + u);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) s += v[u];
+        k = 8;
     }
-    const bool second = p1.tiles > 0 && i4 >= p1.ws_off;
+    for (; k + 8 <= splits; k += 8) {
+        f32x2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld(k + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splits; ++k) s += ld(k);
+    const bool second = p1.tiles > 0 && i2 >= p1.ws_off;
     const TnProb& P = second ? p1 : p0;
-    const size_t j = i4 - P.ws_off, nk = (size_t)P.N * P.Kp;
+    const size_t j = i2 - P.ws_off, nk = (size_t)P.N * P.Kp;
     u16* o;
     if (j < nk) o = P.C + (j / P.Kp) * P.ldc + (j % P.Kp);
     else o = P.colsum + (j - nk);
-    *reinterpret_cast<u32x2*>(o) = u32x2{(uint32_t)from_f32<T>(s[0]) | ((uint32_t)from_f32<T>(s[1]) << 16),
-                                        (uint32_t)from_f32<T>(s[2]) | ((uint32_t)from_f32<T>(s[3]) << 16)};
+    *reinterpret_cast<uint32_t*>(o) = pack2<T>(s[0], s[1]);
 }
 
 static int tn_check(const char* fn, const void* C, const void* cs, const void* A, const void* B, int M, int N, int Kp, int lda, int ldb,
@@ -210,7 +225,7 @@ static int tn_launch(const TnProb& p0, const TnProb& p1, float* ws, size_t slab,
     } else {
         gemm_tn_k<T, true><<<grid, block, 0, st>>>(p0, p1, ws, slab, M / splits);
         MM_CHECK_LAUNCH();
-        splitk_reduce_k<T><<<(unsigned)((slab / 4 + 255) / 256), 256, 0, st>>>(p0, p1, ws, slab, splits);
+        splitk_reduce_k<T><<<(unsigned)((slab / 2 + 255) / 256), 256, 0, st>>>(p0, p1, ws, slab, splits);
         MM_CHECK_LAUNCH();
     }
     return MM_OK;
