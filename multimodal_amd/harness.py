@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import mpu
+from .checkpointing import checkpoint_policy
 from .model import LayerNorm, ParallelTransformerLayer, add_adapters, gpt2_attention_mask_func
 
 CONFIGS = {
@@ -118,6 +119,13 @@ class MagmaStack(nn.Module):
             self._mask = torch.triu(torch.ones(s, s, dtype=torch.bool, device=device), 1).view(1, 1, s, s)
         return self._mask
 
+    def _run_layers(self, start, stop):
+        def run(x, mask):
+            for layer in self.layers[start:stop]:
+                x = layer(x, mask)
+            return x
+        return run
+
     def forward(self, enc_out, tokens, labels, loss_mask):
         """enc_out [b, P, enc_dim] | None, tokens [b, s] int64, labels [b, s], loss_mask [b, s] float -> scalar loss."""
         b, s = tokens.shape
@@ -125,8 +133,14 @@ class MagmaStack(nn.Module):
         # gather + [prefix | text[:, :s-P]] + [b,s,h] -> [s,b,h] in one kernel
         x = Fn.embed_prefix(pre, self.word_embeddings.weight, tokens)
         mask = self.attention_mask(s, x.device)
-        for layer in self.layers:
-            x = layer(x, mask)
+        for start, stop, recompute in checkpoint_policy(len(self.layers), self.cfg.get("checkpoint_activations", False),
+                                                        self.cfg.get("checkpoint_num_layers", 1)):
+            if recompute and torch.is_grad_enabled():  # gpt2_model.py:123-132
+                if not x.requires_grad:
+                    x = x.detach().requires_grad_(True)  # the re-entrant recompute needs a differentiable input
+                x = mpu.checkpoint(self._run_layers(start, stop), x, mask)
+            else:
+                x = self._run_layers(start, stop)(x, mask)
         x = x.transpose(0, 1).contiguous()
         logits, _ = self.final_linear(self.final_norm(x))
         return Fn.masked_cross_entropy(logits, labels, loss_mask)
