@@ -224,6 +224,14 @@ int mm_cross_entropy_fwd(float* loss, float* lse, const void* logits, const int6
 /* dlogits[t, v] = (softmax(logits[t])[v] - [v == label[t]]) * row_scale[t]; may alias logits. */
 int mm_cross_entropy_bwd(void* dlogits, const void* logits, const int64_t* labels, const float* lse,
                          const float* row_scale, int T, int V, int dtype, void* stream);
+/* Loss and gradient in one pass, for the masked-mean loss of megatron/model/gpt2_model.py:52-70 whose per-row gradient
+ * weight row_weight[t] = loss_mask[t] / sum(loss_mask) is known at forward time: loss[t] and lse[t] as mm_cross_entropy_fwd,
+ * and logits[t, :] is OVERWRITTEN with (softmax(logits[t]) - onehot(label[t])) * row_weight[t] (the caller scales what it
+ * derives from that by the loss's upstream gradient).  A block keeps its row in registers: V <= mm_cross_entropy_fwd_grad_max_v()
+ * (65536), larger V returns MM_EUNSUPPORTED. */
+int mm_cross_entropy_fwd_grad(float* loss, float* lse, void* logits, const int64_t* labels, const float* row_weight,
+                              int T, int V, int dtype, void* stream);
+int mm_cross_entropy_fwd_grad_max_v(void);
 
 /* ------------------------------------------------------------------ embedding + image prefix
  * The step in front of the first layer in one pass: word-embedding gather, `cat((image_prefix, text[:, :s-P]), dim=1)` and

@@ -56,6 +56,8 @@ PROTOTYPES = {
     "mm_attn_bwd_rotary": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_cross_entropy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_cross_entropy_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mm_cross_entropy_fwd_grad": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p]),
+    "mm_cross_entropy_fwd_grad_max_v": (c_int, []),
     "mm_embed_prefix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "mm_adam_chunk_elems": (c_int, []),
     "mm_adam_step": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p] + [c_float] * 6 + [c_int, c_int, c_void_p]),

@@ -90,6 +90,96 @@ __global__ __launch_bounds__(256) void ce_bwd_k(u16* __restrict__ dlogits, const
     }
 }
 
+// Forward and gradient in ONE pass over the logits, for callers that know the per-row gradient weight at forward time (the
+// masked-mean loss of gpt2_model.py:52-70: w[row] = mask[row] / sum(mask)): the block keeps its whole row in registers
+// (NT threads x MAXCH 16-byte chunks), so the logits are read once and the gradient (softmax - onehot) * w[row] is written
+// over them.  Against ce_fwd_k + ce_bwd_k this drops one of the two reads of the [T, V] tensor (786 MiB at the 410M shapes).
+template <typename T, int NT, int MAXCH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void ce_fwd_grad_k(float* __restrict__ loss, float* __restrict__ lse_out, u16* __restrict__ logits,
+                                                    const long long* __restrict__ labels, const float* __restrict__ row_w, int V) {
+    constexpr int NW = NT / 64;
+    __shared__ float sred[NW];
+    __shared__ float sbc[2];
+    const size_t row = blockIdx.x;
+    u16* x = logits + row * (size_t)V;
+    const int nch = V >> 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32x4 raw[MAXCH];
+    // the row stays PACKED between the three passes (64 registers): without this the compiler keeps the unpacked floats of
+    // one pass alive for the next and the kernel drops to one block per CU
+    auto repack = [&]() {
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) asm volatile("" : "+v"(raw[i][0]), "+v"(raw[i][1]), "+v"(raw[i][2]), "+v"(raw[i][3]));
+    };
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {  // every load of the row is in flight before the first use
+        const int c = threadIdx.x + i * NT;
+        if (c < nch) raw[i] = *reinterpret_cast<const u32x4*>(x + (size_t)c * 8);
+    }
+    const long long lab = labels[row];
+    const float w = row_w[row];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        if (threadIdx.x + i * NT < nch) {
+            float v[8];
+            unpack8<T>(raw[i], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, v[j]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) sred[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float M = sred[0];
+        for (int k = 1; k < NW; ++k) M = fmaxf(M, sred[k]);
+        sbc[0] = M;
+    }
+    __syncthreads();
+    m = sbc[0];
+    repack();
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        if (threadIdx.x + i * NT < nch) {
+            float v[8];
+            unpack8<T>(raw[i], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) l += __expf(v[j] - m);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    if (lane == 0) sred[wave] = l;  // every wave has read sbc[0]/sred of the max round before the barrier above
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float L = sred[0];
+        for (int k = 1; k < NW; ++k) L += sred[k];
+        const float lse = m + __logf(L);
+        const float tgt = (lab >= 0 && lab < V) ? to_f32<T>(x[lab]) : 0.f;  // x[lab] is overwritten only after the next barrier
+        lse_out[row] = lse;
+        loss[row] = lse - tgt;
+        sbc[1] = lse;
+    }
+    __syncthreads();
+    const float lse = sbc[1];
+    repack();
+    const int labi = (int)lab;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = threadIdx.x + i * NT;
+        if (c < nch) {
+            float v[8], o[8];
+            unpack8<T>(raw[i], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__expf(v[j] - lse) - ((c * 8 + j) == labi ? 1.f : 0.f)) * w;
+            *reinterpret_cast<u32x4*>(x + (size_t)c * 8) = pack8<T>(o);
+        }
+    }
+}
+
 }  // namespace mm
 
 using namespace mm;
@@ -115,6 +205,29 @@ extern "C" int mm_cross_entropy_bwd(void* dlogits, const void* logits, const int
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using TT = decltype(t);
         ce_bwd_k<TT><<<T, 256, 0, (hipStream_t)stream>>>((u16*)dlogits, (const u16*)logits, (const long long*)labels, lse, row_scale, V);
+        MM_CHECK_LAUNCH();
+        return (int)MM_OK;
+    });
+}
+
+constexpr int CE_NT = 512, CE_MAXCH = 16;  // a row of up to 512 * 16 * 8 = 65536 logits lives in one block's registers
+
+extern "C" int mm_cross_entropy_fwd_grad_max_v() { return CE_NT * CE_MAXCH * 8; }
+
+extern "C" int mm_cross_entropy_fwd_grad(float* loss, float* lse, void* logits, const int64_t* labels, const float* row_weight,
+                                         int T, int V, int dtype, void* stream) {
+    MM_CHECK_ARG(loss && lse && logits && labels && row_weight, "mm_cross_entropy_fwd_grad: null pointer");
+    MM_CHECK_ARG(T > 0 && V > 0 && V % 8 == 0, "mm_cross_entropy_fwd_grad: T=%d V=%d (V must be a positive multiple of 8)", T, V);
+    MM_CHECK_ARG(aligned16(logits), "mm_cross_entropy_fwd_grad: logits must be 16-byte aligned");
+    if (V > CE_NT * CE_MAXCH * 8) {
+        set_error("mm_cross_entropy_fwd_grad: V=%d exceeds the %d logits a block keeps in registers (use mm_cross_entropy_fwd + _bwd)",
+                  V, CE_NT * CE_MAXCH * 8);
+        return MM_EUNSUPPORTED;
+    }
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using TT = decltype(t);
+        ce_fwd_grad_k<TT, CE_NT, CE_MAXCH><<<T, CE_NT, 0, (hipStream_t)stream>>>(loss, lse, (u16*)logits, (const long long*)labels,
+                                                                                 row_weight, V);
         MM_CHECK_LAUNCH();
         return (int)MM_OK;
     });

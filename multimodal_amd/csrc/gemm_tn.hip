@@ -54,16 +54,23 @@ __global__ __launch_bounds__(256) void gemm_tn_k(TnProb p0, TnProb p1, float* __
     typedef typename M32<T>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES];  // [buf][A | B]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const bool second = (int)blockIdx.x >= p0.tiles;  // workgroup-uniform
+    // Workgroups are dealt to the 8 XCDs round-robin in launch order, and each XCD has its own L2.  The adapter problems are
+    // one tile wide in N or in Kp, so all 8 tiles of a problem in one token slice read the SAME narrow operand slice
+    // (dpre / h1): launch order would put them on 8 different XCDs and fetch that slice 8 times.  Within every block of 64
+    // launch ids, XCD x takes work ids 8x .. 8x+7 (tile fastest), i.e. one (problem, slice) group per XCD at a time.
+    const unsigned lid = blockIdx.x + gridDim.x * blockIdx.y, total = gridDim.x * gridDim.y;
+    const unsigned wid = lid < (total & ~63u) ? (lid & ~63u) + (lid & 7u) * 8u + ((lid >> 3) & 7u) : lid;
+    const int bx = (int)(wid % gridDim.x), by = (int)(wid / gridDim.x);
+    const bool second = bx >= p0.tiles;  // workgroup-uniform
     const TnProb& P = second ? p1 : p0;
-    const int tile = second ? (int)blockIdx.x - p0.tiles : (int)blockIdx.x;
+    const int tile = second ? bx - p0.tiles : bx;
     const u16* __restrict__ A = P.A;
     const u16* __restrict__ B = P.B;
     const int N = P.N, Kp = P.Kp, lda = P.lda, ldb = P.ldb, ldc = P.ldc, tiles_k = P.tiles_k;
     const bool CS = P.colsum != nullptr;
     const int tn = tile / tiles_k, tk = tile % tiles_k;
     const int n0 = tn * TN_BT, k0 = tk * TN_BT;
-    const int m_begin = blockIdx.y * rows_per_split;
+    const int m_begin = by * rows_per_split;
     const int ntile = rows_per_split / 64;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_tn_k(TnProb p0, TnProb p1, float* __
         if (t + 1 < ntile) body(t + 1, std::integral_constant<int, 1>{});
     }
     // D[row = n (registers)][col = kp (lane)]
-    float* wsp = ws + (size_t)blockIdx.y * slab + P.ws_off;
+    float* wsp = ws + (size_t)by * slab + P.ws_off;
     u16* C = P.C;
 #pragma unroll
     for (int i = 0; i < 2; ++i)

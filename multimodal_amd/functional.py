@@ -428,6 +428,45 @@ def masked_cross_entropy(logits, labels, loss_mask):
     return torch.sum(losses * lm) / lm.sum()
 
 
+class LmHeadLossFn(torch.autograd.Function):
+    """Bias-free LM head (transformer.py:816-839) + masked-mean cross entropy (gpt2_model.py:52-70) as ONE node, so that the
+    [T, V] logits are read once: the loss kernel leaves (softmax - onehot) * mask / sum(mask) in the logits buffer, and the
+    backward feeds that buffer to the data- / weight-gradient GEMMs and scales their [T, h] / [V, h] results by the loss's
+    upstream gradient (a device scalar: no host sync, graph-capturable).  Same loss bits as `linear` +
+    `masked_cross_entropy` up to the last place of logsumexp; bf16 only - with fp16 the unscaled gradient would lose what
+    the reference's loss scaling protects - and tensor-parallel size 1 (the vocab-parallel loss needs its three exchanges)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, labels, loss_mask):
+        x2 = _flat2d(x)
+        logits = ops.gemm_nt(x2, weight, None, _lib.EPI_NONE)
+        lm = loss_mask.reshape(-1).float()
+        den = lm.sum()
+        losses, _ = ops.cross_entropy_fwd_grad(logits, labels.reshape(-1).contiguous(), (1.0 / den) * lm)
+        ctx.save_for_backward(x2, weight, logits)  # `logits` now holds the gradient for an upstream gradient of 1
+        ctx.xshape = x.shape
+        return torch.sum(losses * lm) / den
+
+    @staticmethod
+    def backward(ctx, gup):
+        x2, weight, g = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = (ops.gemm_nt(g, weight_t(weight)) * gup).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(g, x2) * gup
+        return dx, dw, None, None
+
+
+def lm_head_loss_supported(x, weight):
+    return x.dtype == torch.bfloat16 and ops.cross_entropy_fwd_grad_supported(weight.size(0))
+
+
+def lm_head_loss(x, weight, labels, loss_mask):
+    """x [b, s, h] (after the final norm), weight [V, h], labels / loss_mask [b, s] -> scalar loss."""
+    return LmHeadLossFn.apply(x, weight, labels, loss_mask)
+
+
 class EmbedPrefixFn(torch.autograd.Function):
     """Word embeddings + image-prefix concat + transpose to [s, b, h] (megatron/model/word_embeddings.py:135-205,
     gpt2_model.py:73-77) for a FROZEN embedding table: only the prefix rows carry a gradient back."""

@@ -142,7 +142,12 @@ class MagmaStack(nn.Module):
             else:
                 x = self._run_layers(start, stop)(x, mask)
         x = x.transpose(0, 1).contiguous()
-        logits, _ = self.final_linear(self.final_norm(x))
+        x = self.final_norm(x)
+        w = self.final_linear.weight
+        if (self.cfg.get("fused_head_loss", True) and torch.is_grad_enabled() and mpu.get_model_parallel_world_size() == 1
+                and Fn.lm_head_loss_supported(x, w)):
+            return Fn.lm_head_loss(x, w, labels, loss_mask)  # head + loss, logits read once
+        logits, _ = self.final_linear(x)
         return Fn.masked_cross_entropy(logits, labels, loss_mask)
 
 

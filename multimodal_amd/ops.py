@@ -468,6 +468,24 @@ def cross_entropy_bwd(logits, labels, lse, row_scale, out=None):
     return out
 
 
+def cross_entropy_fwd_grad_supported(V):
+    return V % 8 == 0 and V <= get_lib().mm_cross_entropy_fwd_grad_max_v()
+
+
+def cross_entropy_fwd_grad(logits, labels, row_weight):
+    """One pass: (loss [T], lse [T]) and `logits` OVERWRITTEN with (softmax - onehot) * row_weight[t]."""
+    _need_cuda(logits, labels, row_weight)
+    T, V = logits.shape
+    if not logits.is_contiguous() or row_weight.dtype != torch.float32 or row_weight.numel() != T or labels.numel() != T:
+        raise ValueError("cross_entropy_fwd_grad: logits [T, V] contiguous, labels [T], row_weight [T] fp32")
+    loss = torch.empty(T, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(T, dtype=torch.float32, device=logits.device)
+    check(get_lib().mm_cross_entropy_fwd_grad(loss.data_ptr(), lse.data_ptr(), logits.data_ptr(), labels.data_ptr(),
+                                              row_weight.data_ptr(), T, V, dtype_code(logits.dtype), _stream()),
+          "cross_entropy_fwd_grad")
+    return loss, lse
+
+
 # ---------------------------------------------------------------------------- embedding + image prefix
 def embed_prefix(table, tokens, prefix=None):
     """[s, b, h] input of the first layer: out[si, bi] = prefix[bi, si] for si < P else table[tokens[bi, si - P]]

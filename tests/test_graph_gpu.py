@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 def test_hip_graph_replay_equals_eager_step(cuda_device):
     from multimodal_amd import harness, mpu
+    mpu.destroy_model_parallel()
     mpu.initialize_model_parallel(1)
     mpu.model_parallel_cuda_manual_seed(7)
     cfg = harness.CONFIGS["tiny"]

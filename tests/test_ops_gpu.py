@@ -404,6 +404,41 @@ def test_cross_entropy_fwd_bwd(ops, cuda_device, T, V):
     ulp_close(d, x.grad.bfloat16(), torch.bfloat16, ulps=1, atol=1e-7)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,V", [(96, 50304), (33, 1024), (8, 65536), (5, 8), (16, 4104)])
+def test_cross_entropy_fwd_grad_one_pass(ops, cuda_device, dt, T, V):
+    """Loss + gradient in one pass over the logits (the row lives in registers) against the two-pass kernels and torch fp32."""
+    torch.manual_seed(T + V)
+    dtype = DT[dt]
+    logits = (torch.randn(T, V) * 3).to(dtype)
+    labels = torch.randint(0, V, (T,))
+    w = torch.rand(T)
+    w[::3] = 0.0  # masked tokens
+    lg, lb, wg = logits.to(cuda_device), labels.to(cuda_device), w.to(cuda_device)
+    loss2, lse2 = ops.cross_entropy_fwd(lg, lb)
+    grad2 = ops.cross_entropy_bwd(lg, lb, lse2, wg)
+    buf = lg.clone()
+    loss1, lse1 = ops.cross_entropy_fwd_grad(buf, lb, wg)
+    assert (lse1 - lse2).abs().max() <= 4e-6 * lse2.abs().max() + 1e-6
+    assert (loss1 - loss2).abs().max() <= 4e-6 * lse2.abs().max() + 1e-6
+    ulp_close(buf, grad2, dtype, ulps=1, atol=1e-7)
+    assert (buf[::3] == 0).all()
+    x = logits.float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(x, labels, reduction="none")
+    (ref * w).sum().backward()
+    assert (loss1.cpu() - ref.detach()).abs().max() <= 2e-4
+    ulp_close(buf, x.grad.to(dtype), dtype, ulps=1, atol=1e-7)
+
+
+def test_cross_entropy_fwd_grad_rejects_rows_beyond_registers(ops, cuda_device):
+    from multimodal_amd._lib import get_lib
+    vmax = get_lib().mm_cross_entropy_fwd_grad_max_v()
+    assert vmax == 65536 and ops.cross_entropy_fwd_grad_supported(50304) and not ops.cross_entropy_fwd_grad_supported(vmax + 8)
+    lg = torch.zeros(2, vmax + 8, dtype=torch.bfloat16, device=cuda_device)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        ops.cross_entropy_fwd_grad(lg, torch.zeros(2, dtype=torch.int64, device=cuda_device), torch.ones(2, device=cuda_device))
+
+
 # ------------------------------------------------------------------ weight-gradient GEMM (TN, split-K)
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,Kp", [(64, 128, 128), (256, 128, 256), (8192, 128, 1024), (8192, 1024, 128), (1024, 384, 128),

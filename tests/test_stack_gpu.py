@@ -6,7 +6,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _stack(cuda_device, seed, **over):
-    from multimodal_amd import harness
+    from multimodal_amd import harness, mpu
+    mpu.model_parallel_cuda_manual_seed(seed)  # the GPU initialisers draw from the tracker's model-parallel stream
     cfg = dict(harness.CONFIGS["tiny"])
     cfg.update(add_adapters=True, freeze_lm=True, image_embed_dropout_prob=0.1)
     cfg.update(over)
@@ -63,3 +64,52 @@ def test_activation_recompute_is_bit_identical(cuda_device, interval):
     assert len(g0) == len(g1) > 0
     for x, y in zip(g0, g1):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("freeze", [True, False])
+def test_fused_head_loss_equals_linear_plus_masked_cross_entropy(cuda_device, freeze):
+    """LM head + masked-mean loss as one node (logits read once, gradient left in the logits buffer) against
+    the two-node path: same loss to the last place of logsumexp, same gradients to one bf16 ulp of the gradient's scale;
+    an upstream gradient other than 1 (loss scaling, gradient accumulation) scales the head's outputs."""
+    from multimodal_amd import functional as Fn
+    torch.manual_seed(3)
+    b, s, h, V = 2, 64, 256, 1024
+    x = torch.randn(b, s, h, device=cuda_device).bfloat16()
+    w = (torch.randn(V, h, device=cuda_device) * 0.05).bfloat16()
+    labels = torch.randint(0, V, (b, s), device=cuda_device)
+    mask = (torch.rand(b, s, device=cuda_device) > 0.2).float()
+
+    def run(fused, up):
+        xx = x.clone().requires_grad_(True)
+        ww = w.clone().requires_grad_(not freeze)
+        if fused:
+            assert Fn.lm_head_loss_supported(xx, ww)
+            loss = Fn.lm_head_loss(xx, ww, labels, mask)
+        else:
+            loss = Fn.masked_cross_entropy(Fn.linear(xx, ww), labels, mask)
+        (loss * up).backward()
+        return loss.detach(), xx.grad, ww.grad
+
+    for up in (1.0, 0.25):
+        l0, dx0, dw0 = run(False, up)
+        l1, dx1, dw1 = run(True, up)
+        assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
+        assert (dx0.float() - dx1.float()).abs().max() <= 2.0 ** -8 * dx0.float().abs().max()
+        if freeze:
+            assert dw0 is None and dw1 is None
+        else:
+            assert (dw0.float() - dw1.float()).abs().max() <= 2.0 ** -8 * dw0.float().abs().max()
+
+
+def test_stack_uses_the_fused_head_loss_and_matches_the_unfused_stack(cuda_device):
+    from multimodal_amd import harness, mpu
+    mpu.destroy_model_parallel()
+    mpu.initialize_model_parallel(1)
+    cfg, fused = _stack(cuda_device, 17)
+    _, plain = _stack(cuda_device, 17, fused_head_loss=False)
+    batch = harness.synthetic_batch(cfg, cuda_device, seed=8)
+    l1, g1 = _loss_and_grads(fused, batch, 5)
+    l0, g0 = _loss_and_grads(plain, batch, 5)
+    assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
+    for a, b in zip(g0, g1):
+        assert (a.float() - b.float()).abs().max() <= 2.0 ** -6 * a.float().abs().max() + 1e-9

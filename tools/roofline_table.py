@@ -25,6 +25,10 @@ ROWS = [
     ("attn_bwd_dq_k<mm::BF16, 64, 0>", "attention backward dQ (+ rotary backward)", "mfma", attn_f * 1.5, "3 products (S and dP recomputed)"),
     ("bottleneck_k<mm::BF16, 1024, 128, 0>", "adapter forward", "hbm", 2.0 * (2 * T * H + T * R), "o in, out + h1 out"),
     ("bottleneck_k<mm::BF16, 1024, 128, 1>", "adapter data gradient", "hbm", 2.0 * (2 * T * H + 2 * T * R), "dy + h1 in, dx + dpre out"),
+    ("bottleneck_dma_k<mm::BF16, 1024, 128, 0, false>", "adapter forward", "hbm", 2.0 * (2 * T * H + T * R), "o in, out + h1 out"),
+    ("bottleneck_dma_k<mm::BF16, 1024, 128, 0, true>", "MLP adapter forward + GPT-J residual tail", "hbm", 2.0 * (4 * T * H + T * R),
+     "o, x, attn in, out + h1 out"),
+    ("bottleneck_dma_k<mm::BF16, 1024, 128, 1, false>", "adapter data gradient", "hbm", 2.0 * (2 * T * H + 2 * T * R), "dy + h1 in, dx + dpre out"),
     ("gemm_tn_k<mm::BF16, true>", "adapter weight + bias gradients (pair)", "hbm", 2.0 * (2 * T * H + 2 * T * R), "o, dy, dpre, h1 read once"),
     ("splitk_reduce_k", "split-K slab reduce of the pair", "hbm", 16 * 4.0 * 2 * (R * H + H) + 2.0 * 2 * R * H, "16 fp32 slabs in, 2 weights out"),
     ("layernorm_fwd_k<mm::BF16, 2, true>", "dual LayerNorm forward", "hbm", 6.0 * T * H, "x in, two outputs"),
@@ -33,6 +37,7 @@ ROWS = [
     ("attn_delta_k", "attention backward delta", "hbm", 4.0 * T * H, "dO, O in"),
     ("ce_fwd_k", "cross entropy forward", "hbm", 2.0 * T * V, "logits in"),
     ("ce_bwd_k", "cross entropy backward (in place)", "hbm", 4.0 * T * V, "logits in, gradient out"),
+    ("ce_fwd_grad_k", "cross entropy loss + gradient in one pass (in place)", "hbm", 4.0 * T * V, "logits in, gradient out"),
     ("adam_update_k", "clip + Adam update", "hbm", 28.0 * 13.7e6, "13.7 M parameters x 28 B"),
 ]
 
