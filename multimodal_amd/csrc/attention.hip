@@ -45,6 +45,16 @@ template <typename V> __device__ __forceinline__ void pin(V& v) {
 }
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 
+// Two workgroups share a CU, so every SIMD holds two waves running this same loop.  Left to age-based arbitration the wave in
+// its softmax segment keeps the issue port and the partner's MFMAs trickle in behind it (PMC: matrix pipe and vector port
+// busy 27 % + 45 % with no overlap).  Raising the priority of a wave for the length of its MFMA groups lets each MFMA take
+// its one issue slot per 32 pipe cycles and leaves the rest of the port to the partner's vector work: forward -5.5 %,
+// backward -3.7 % (tools/ab_attn.py, same process), results unchanged.
+__device__ __forceinline__ void mfma_prio(int on) {
+    if (on) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 // mask byte for (q, key); mask row base already selected
 __device__ __forceinline__ bool mask_at(const uint8_t* __restrict__ mrow, int key) { return mrow[key] == 1; }
 
@@ -106,6 +116,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
         const int kv0 = j * 64;
         if (MODE == 1 || kv0 <= wave_last) {  // wave-uniform: skip key tiles entirely above this wave's diagonal
             f32x16 sacc[2];
+            mfma_prio(1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
 #pragma unroll
                 for (int ds = 0; ds < NDS; ++ds) sacc[t] = M32<T>::run(row_frag<T, HD>(ks, 32 * t, ds, lane), qf[ds], sacc[t]);
             }
+            mfma_prio(0);
             // raw scores stay unscaled: max commutes with the positive scale, and p = exp2(fma(s, c, -m)) is one FMA + one exp.
             // The causal compare/select only runs on tiles that touch this wave's diagonal (wave-uniform test).
             if (MODE == 1) {
@@ -162,6 +174,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
             }
             l_run += lsum;
             m_run = m_new;
+            mfma_prio(1);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) o[d] = M32<T>::run(tr_frag<T, HD>(vs, 32 * t + 16 * s2, d, lane), pf, o[d]);
                 }
+            mfma_prio(0);
         }
         if (j + 1 < ntiles) {
             char* nk = smem + (cur ^ 1) * 2 * TL::BYTES;
@@ -354,11 +368,13 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
                 f32x16 sacc, dpacc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sacc[i] = dpacc[i] = 0.f;
+                mfma_prio(1);
 #pragma unroll
                 for (int ds = 0; ds < NDS; ++ds) {
                     sacc = M32<T>::run(row_frag<T, HD>(ks, 32 * t, ds, lane), qf[ds], sacc);
                     dpacc = M32<T>::run(row_frag<T, HD>(vs, 32 * t, ds, lane), dof[ds], dpacc);
                 }
+                mfma_prio(0);
                 if (MODE == 1) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -391,6 +407,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
                         sacc[2 * i + 1] = ds2[1];
                     }
                 }
+                mfma_prio(1);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const frag dsf = M32<T>::cvt8(sacc[8 * s2], sacc[8 * s2 + 1], sacc[8 * s2 + 2], sacc[8 * s2 + 3],
@@ -398,6 +415,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) dq[d] = M32<T>::run(tr_frag<T, HD>(ks, 32 * t + 16 * s2, d, lane), dsf, dq[d]);
                 }
+                mfma_prio(0);
             }
         }
         if (j + 1 < ntiles) {
@@ -505,11 +523,13 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                 f32x16 sacc, dpacc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sacc[i] = dpacc[i] = 0.f;
+                mfma_prio(1);
 #pragma unroll
                 for (int ds = 0; ds < NDS; ++ds) {
                     sacc = M32<T>::run(row_frag<T, HD>(qs, 32 * t, ds, lane), kf[ds], sacc);    // S[q][key]
                     dpacc = M32<T>::run(row_frag<T, HD>(os, 32 * t, ds, lane), vf[ds], dpacc);  // dP[q][key]
                 }
+                mfma_prio(0);
                 float pv[16];
                 // wave-uniform: only tiles on this wave's diagonal (or the ragged last tile) pay for the compare/select
                 const bool need_mask = (wave_first + 31 > q0t + 32 * t) || (q0t + 32 * t + 32 > s);
@@ -564,6 +584,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                         }
                     }
                 }
+                mfma_prio(1);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const frag pf = M32<T>::cvt8(pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3], pv[8 * s2 + 4],
@@ -576,6 +597,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                         dk[d] = M32<T>::run(tr_frag<T, HD>(qs, 32 * t + 16 * s2, d, lane), dsf, dk[d]);  // dK^T += Q^T . dS
                     }
                 }
+                mfma_prio(0);
             }
         }
         if (j + 1 < nqt) {

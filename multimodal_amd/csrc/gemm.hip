@@ -92,10 +92,14 @@ __global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* _
                 fa[i] = *reinterpret_cast<const frag*>(a_base + (offA[i] ^ (kk << 6)));
                 fb[i] = *reinterpret_cast<const frag*>(b_base + (offB[i] ^ (kk << 6)));
             }
+            // two workgroups share a CU: the MFMA block outranks the partner wave's address / epilogue vector work for the issue
+            // port (one slot per 16 pipe cycles keeps the matrix pipe fed); -4..7 % on the N = h shapes, tools/ab_gemm_x.py
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mfma<T>::run(fb[ni], fa[mi], acc[ni][mi]);
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
     }
