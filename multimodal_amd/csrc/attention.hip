@@ -55,6 +55,25 @@ __device__ __forceinline__ void mfma_prio(int on) {
     else __builtin_amdgcn_s_setprio(0);
 }
 
+// Combine a value with the one held by the lane 32 away (the other half of the wave) without the LDS round trip of
+// ds_bpermute: v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32 of its second, so with
+// both operands = x every lane ends up holding (lower-half value, upper-half value) of its lane pair.
+__device__ __forceinline__ void half_pair(float x, float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float half_max(float x) {
+    float lo, hi;
+    half_pair(x, lo, hi);
+    return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float half_sum(float x) {
+    float lo, hi;
+    half_pair(x, lo, hi);
+    return lo + hi;
+}
+
 // mask byte for (q, key); mask row base already selected
 __device__ __forceinline__ bool mask_at(const uint8_t* __restrict__ mrow, int key) { return mrow[key] == 1; }
 
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) rmax = fmaxf(rmax, sacc[t][i]);
-            rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+            rmax = half_max(rmax);
             const float m_new = fmaxf(m_run, rmax * scale_log2e);
             // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU issue
             const f32x2 sc2 = {scale_log2e, scale_log2e}, mn2 = {m_new, m_new};
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
         __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = half_sum(l_run);
     const float inv = 1.0f / l_tot;
     if (qrow < s) {
         u16* orow = ctx + ((size_t)qrow * b + bi) * ((size_t)np * HD) + (size_t)hi * HD;
