@@ -12,6 +12,8 @@ biases once per rank (transformer.py:690,703,747-766).
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -141,6 +143,23 @@ class ParallelSelfAttention(nn.Module):
         return self.dense(context)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _branch_streams():
+    """Attention branch and MLP GEMMs of a GPT-J layer on two HIP streams (MM_BRANCH_STREAMS=0 puts them back on one).
+    Measured on one box: eager step 24.7 -> 23.9 ms (the second stream fills launch gaps), graph-replayed step 22.27 ->
+    22.17 ms (the kernels overlap in time - rocprofv3 trace: 203 ms of kernel time in 144 ms - but share the CUs)."""
+    return os.environ.get("MM_BRANCH_STREAMS", "1") != "0"
+
+
 class ParallelTransformerLayer(nn.Module):
     """A single transformer layer, [s, b, h] -> [s, b, h] (megatron/model/transformer.py:644-801)."""
 
@@ -199,13 +218,27 @@ class ParallelTransformerLayer(nn.Module):
                 x1, x2, residual = Fn.dual_layer_norm_res(x, ln1.weight, ln1.bias, ln2.weight, ln2.bias, ln1.eps)
             else:
                 x1, x2 = ln1(x), ln2(x)
-            attention_output, attention_bias = self.attention(x1, attention_mask, layer_past=layer_past)
             no_drop = self.hidden_dropout == 0 or not self.training
             tail = self._fused_adapter_tail() if no_drop else None
+            if tail is None:
+                attention_output, attention_bias = self.attention(x1, attention_mask, layer_past=layer_past)
             if tail is not None:
                 # MAGMA layer: the MLP's adapter is the last kernel, so the residual tail rides on its output store
                 a0, a2 = tail
-                mlp_raw, mlp_bias = self.mlp.attn_block(x2)
+                if _branch_streams() and x2.is_cuda:
+                    # GPT-J parallel residual: the MLP GEMMs and the attention branch only meet in the tail, so they go to two
+                    # HIP streams (the attention kernels are vector-bound, the GEMMs matrix-bound: they share a CU well)
+                    main, side = torch.cuda.current_stream(), _side_stream(x2.device)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        mlp_raw, mlp_bias = self.mlp.attn_block(x2)
+                    attention_output, attention_bias = self.attention(x1, attention_mask, layer_past=layer_past)
+                    main.wait_stream(side)
+                    x2.record_stream(side)       # allocated on one stream, read on the other: the allocator must not
+                    mlp_raw.record_stream(main)  # hand the block out again before that stream has passed the reader
+                else:
+                    attention_output, attention_bias = self.attention(x1, attention_mask, layer_past=layer_past)
+                    mlp_raw, mlp_bias = self.mlp.attn_block(x2)
                 tp1 = mpu.get_model_parallel_world_size() == 1
                 output = Fn.adapter_combine(mlp_raw, a0.weight, a0.bias, a2.weight, a2.bias, residual if tp1 else None,
                                             attention_output, attention_bias, mlp_bias)

@@ -113,3 +113,27 @@ def test_stack_uses_the_fused_head_loss_and_matches_the_unfused_stack(cuda_devic
     assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
     for a, b in zip(g0, g1):
         assert (a.float() - b.float()).abs().max() <= 2.0 ** -6 * a.float().abs().max() + 1e-9
+
+
+def test_two_stream_layer_equals_one_stream_layer(cuda_device, monkeypatch):
+    """The GPT-J layer runs its attention branch and its MLP GEMMs on two HIP streams (model/transformer.py): same kernels on
+    the same data, so loss and gradients must equal the single-stream run bit for bit, step after step (a missing
+    dependency between the streams would show up here as a mismatch)."""
+    from multimodal_amd import harness, mpu
+    mpu.destroy_model_parallel()
+    mpu.initialize_model_parallel(1)
+    cfg, model = _stack(cuda_device, 19, num_layers=4)
+    batches = [harness.synthetic_batch(cfg, cuda_device, seed=40 + i) for i in range(3)]
+    results = {}
+    for mode in ("0", "1", "0", "1"):
+        monkeypatch.setenv("MM_BRANCH_STREAMS", mode)
+        out = [_loss_and_grads(model, b, 9) for b in batches]
+        torch.cuda.synchronize()
+        if mode in results:
+            ref = results[mode]
+        else:
+            ref = results.setdefault(mode, out)
+        for (l0, g0), (l1, g1) in zip(results["0"], out):
+            assert torch.equal(l0, l1)
+            for a, b in zip(g0, g1):
+                assert torch.equal(a, b)
