@@ -16,8 +16,9 @@
 //     accumulator registers are directly the B operand of the second product (P.V, dS.K, P^T.dO, dS^T.Q)
 //     with no LDS round trip;
 //   * the A operand of those second products needs the streamed tile transposed: it is read from the SAME
-//     row-major LDS image with ds_read_b64_tr_b16.  The image has a 64-byte row pad and a 4-way XOR on the
-//     16-byte chunk index, which makes both the row reads (ds_read_b128) and the transposed reads conflict-free;
+//     row-major LDS image with ds_read_b64_tr_b16.  An XOR on the 16-byte chunk index (head size 64: unpadded 128-byte
+//     rows; head size 128: rows padded by 64 bytes; mfma32.h) makes both the row reads (ds_read_b128) and the transposed
+//     reads conflict-free;
 //   * softmax in the exp2 domain with fp32 statistics; fp32 accumulation everywhere.
 // mask_mode 0 = implicit causal, -inf above the diagonal, fully masked key tiles are skipped
 //               (semantics of scaled_upper_triang_masked_softmax.h:143-260);

@@ -30,12 +30,24 @@ template <> struct M32<F16> {
 };
 
 // ---- LDS image of a streamed [64 rows][HD] tile
+// HD = 128 (and the TN kernel's 128-column tiles): 64-byte row pad, so that the 4 rows of a transposed-read pass start 48
+// banks apart and cover all 64 banks, + a 4-way XOR of the 16-byte chunk index for the row reads.
+// HD = 64: NO pad (128-byte rows, 8 KiB per tile instead of 12: a workgroup's K/V ring is 32 KiB and four workgroups fit a
+// CU).  A row is two 64-byte halves; the XOR value of a row, bits (2,1,0) = (row>>1 &1, row>>2 &1, row>>3 &1), does both jobs:
+//   * transposed reads: a pass reads 64 bytes of each of rows 4a..4a+3; row parity picks banks 0-31 / 32-63 and bit 2 of the XOR
+//     (row>>1 &1) flips the 64-byte half -> the four rows land on the four bank quarters;
+//   * row reads / stores (16 lanes = 16 consecutive rows at one chunk index, or 2 rows x 8 chunks): within one parity the XOR
+//     value runs through all 8 values over 16 consecutive rows -> 16 distinct 4-bank groups.
 template <int HD> struct Tile {
-    static constexpr int STRIDE = HD * 2 + 64;        // bytes per row (row pad: 4 tr-read rows cover all 64 banks)
+    static constexpr int STRIDE = HD == 64 ? 128 : HD * 2 + 64;  // bytes per row
     static constexpr int BYTES = 64 * STRIDE;
     static constexpr int CPR = HD / 8;                // 16-byte chunks per row
     static constexpr int NCH = 64 * CPR / 256;        // chunks per thread per tile
-    static __device__ __forceinline__ int off(int row, int chunk) { return row * STRIDE + ((chunk ^ ((row >> 2) & 3)) << 4); }
+    static __device__ __forceinline__ int swz(int row) {
+        if constexpr (HD == 64) return (((row >> 1) & 1) << 2) | ((row >> 1) & 2) | ((row >> 3) & 1);
+        else return (row >> 2) & 3;
+    }
+    static __device__ __forceinline__ int off(int row, int chunk) { return row * STRIDE + ((chunk ^ swz(row)) << 4); }
 };
 
 template <int HD>
@@ -73,8 +85,8 @@ __device__ __forceinline__ typename M32<T>::frag tr_frag(const char* lds, int kb
     const int col = 32 * dblk + 16 * (g & 1) + 4 * p;
     const int ra = kb + 4 * hh + q;
     const int rb = ra + 8;
-    const char* pa = lds + ra * Tile<HD>::STRIDE + ((((col >> 3) ^ ((ra >> 2) & 3))) << 4) + (col & 7) * 2;
-    const char* pb = lds + rb * Tile<HD>::STRIDE + ((((col >> 3) ^ ((rb >> 2) & 3))) << 4) + (col & 7) * 2;
+    const char* pa = lds + Tile<HD>::off(ra, col >> 3) + (col & 7) * 2;
+    const char* pb = lds + Tile<HD>::off(rb, col >> 3) + (col & 7) * 2;
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
     const s16x8 v = s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
