@@ -231,33 +231,6 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
     }
 }
 
-// =====================================================================================  backward: delta
-// delta[b, np, s] = sum_d dO[q][d] * O[q][d]
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_delta_k(float* __restrict__ delta, const u16* __restrict__ dctx,
-                                                    const u16* __restrict__ ctx, int s, int b, int np) {
-    constexpr int LPR = HD / 8;  // lanes per row
-    const size_t nrows = (size_t)s * b * np;
-    const size_t row = ((size_t)blockIdx.x * 256 + threadIdx.x) / LPR;
-    const int c = threadIdx.x % LPR;
-    float acc = 0.f;
-    if (row < nrows) {
-        float a[8], o[8];
-        unpack8<T>(*reinterpret_cast<const u32x4*>(dctx + row * HD + c * 8), a);
-        unpack8<T>(*reinterpret_cast<const u32x4*>(ctx + row * HD + c * 8), o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
-    }
-#pragma unroll
-    for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (row < nrows && c == 0) {
-        const size_t si = row / ((size_t)b * np);
-        const size_t rem = row % ((size_t)b * np);
-        delta[rem * s + si] = acc;  // rem = bi*np + hi
-    }
-}
-
-
 // =====================================================================================  backward: gradient row store
 // One lane's share of a [HD] gradient row in the 32x32 accumulator layout: register 4*g4 + e of block d is head dim
 // 32*d + 8*g4 + 4*hh + e.  The row is scaled and rounded to T; with ROT > 0 the first ROT dims then go through the
@@ -316,8 +289,9 @@ __device__ __forceinline__ void store_grad_row_rt(u16* __restrict__ dst, const f
 // =====================================================================================  backward: dQ
 template <typename T, int HD, int MODE>
 __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
-                                                     const float* __restrict__ lse, const float* __restrict__ delta,
-                                                     const u16* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                     const u16* __restrict__ ctx, const float* __restrict__ lse,
+                                                     float* __restrict__ delta, const u16* __restrict__ qkv,
+                                                     const uint8_t* __restrict__ mask,
                                                      int mask_batches, int s, int b, int np, float scale_log2e, float scale,
                                                      const u16* __restrict__ cos_t, const u16* __restrict__ sin_t, int rot_d,
                                                      int rot_off) {
@@ -343,7 +317,23 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
         dof[ds] = *reinterpret_cast<const frag*>(dorow + 16 * ds + 8 * hh);
     }
     const float lse2_ld = lse[((size_t)bi * np + hi) * s + qrow_c] * kLog2e;
-    const float dlt_ld = delta[((size_t)bi * np + hi) * s + qrow_c];
+    // delta[q] = sum_d dO[q][d] * O[q][d]: this wave holds its 32 rows of dO as MFMA fragments (half the dims per lane half), so
+    // the row sums cost one O-row load and 4*NDS FMAs here and replace a separate pass over dO and O; the dK/dV kernel, which
+    // is launched after this one, reads them from `delta`
+    float dlt_ld = 0.f;
+    {
+        const u16* orow = ctx + ((size_t)qrow_c * b + bi) * ((size_t)np * HD) + (size_t)hi * HD;
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            float a[8], o[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(dorow + 16 * ds + 8 * hh), a);
+            unpack8<T>(*reinterpret_cast<const u32x4*>(orow + 16 * ds + 8 * hh), o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dlt_ld += a[e] * o[e];
+        }
+        dlt_ld = half_sum(dlt_ld);
+        if (hh == 0 && qrow < s) delta[((size_t)bi * np + hi) * s + qrow] = dlt_ld;
+    }
 
     const int blk_last = min(q0 + 127, s - 1);
     const int ntiles = (MODE == 0) ? (blk_last / 64 + 1) : ((s + 63) / 64);
@@ -656,20 +646,17 @@ template <typename T, int HD>
 static int launch_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
                       const uint8_t* mask, int mode, int mb, int s, int b, int np, float scale, const u16* cs, const u16* sn,
                       int rd, int ro, hipStream_t st) {
-    const size_t nrows = (size_t)s * b * np;
-    const size_t nthreads = nrows * (HD / 8);
-    attn_delta_k<T, HD><<<(unsigned)((nthreads + 255) / 256), 256, 0, st>>>(delta, (const u16*)dctx, (const u16*)ctx, s, b, np);
-    MM_CHECK_LAUNCH();
     dim3 grid(b * np, (s + 127) / 128), block(256);  // head-fast, heavy blocks first (see launch_fwd)
     const float sl2 = scale * kLog2e;
+    // dQ first: it also leaves delta[b, np, s] for the dK/dV kernel behind it on the stream
     if (mode == 0) {
+        attn_bwd_dq_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, (const u16*)ctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale, cs, sn, rd, ro);
+        MM_CHECK_LAUNCH();
         attn_bwd_dkv_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale, cs, sn, rd, ro);
-        MM_CHECK_LAUNCH();
-        attn_bwd_dq_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale, cs, sn, rd, ro);
     } else {
-        attn_bwd_dkv_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale, cs, sn, rd, ro);
+        attn_bwd_dq_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, (const u16*)ctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale, cs, sn, rd, ro);
         MM_CHECK_LAUNCH();
-        attn_bwd_dq_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale, cs, sn, rd, ro);
+        attn_bwd_dkv_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale, cs, sn, rd, ro);
     }
     MM_CHECK_LAUNCH();
     return MM_OK;

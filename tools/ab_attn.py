@@ -30,4 +30,4 @@ def bwd():
 
 
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
-    print("fwd %.1f us  bwd %.1f us (delta + dkv + dq)" % (timeit(fwd, n=60, warm=10), timeit(bwd, n=40, warm=5)))
+    print("fwd %.1f us  bwd %.1f us (dq with the delta row sums, then dkv)" % (timeit(fwd, n=60, warm=10), timeit(bwd, n=40, warm=5)))

@@ -52,7 +52,7 @@ def bench_attn():
     def bwd():
         return ops.attn_bwd(dctx, ctx, lse, qkvs[i[0] % 4], S, B, NP, HN, scale, None)
     t = timeit(bwd)
-    print("attn_bwd   %8.1f us  %7.1f TF/s (delta + dkv + dq)" % (t, 2.5 * fl / t / 1e6))
+    print("attn_bwd   %8.1f us  %7.1f TF/s (dq with the delta row sums, then dkv)" % (t, 2.5 * fl / t / 1e6))
 
 
 def bench_gemm():
