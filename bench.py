@@ -234,14 +234,25 @@ def main():
             graph_step(i)
         dt_graph, loss = timed(graph_step)
         losses.append(float(loss.detach()))
-    # eager launches of the same K steps, with HIP events around the roofline kernel on its launch stream
+    dt_plain = None
+    if dt_graph is None:  # no graph: the reported value is an eager region with the layer's two streams as configured
+        dt_plain, loss = timed(step)
+    # eager launches of the same K steps, with HIP events around the roofline kernel on its launch stream.  The layer keeps
+    # to ONE stream here: on two, the attention kernels of the other stream share the CUs with the probed GEMM and the
+    # events would time that mix, not the kernel.
     probe = {"epilogue": _lib.EPI_BIAS_GELU_TANH if cfg["bias_gelu_fusion"] else _lib.EPI_BIAS_GELU_ERF, "events": []}
     if rank == 0:
         ops.GEMM_EVENT_PROBE = probe
+    streams_env = os.environ.get("MM_BRANCH_STREAMS")
+    os.environ["MM_BRANCH_STREAMS"] = "0"
     dt_eager, loss = timed(step)
+    if streams_env is None:
+        del os.environ["MM_BRANCH_STREAMS"]
+    else:
+        os.environ["MM_BRANCH_STREAMS"] = streams_env
     ops.GEMM_EVENT_PROBE = None
     losses.append(float(loss.detach()))
-    dt = dt_graph if dt_graph is not None else dt_eager
+    dt = dt_graph if dt_graph is not None else dt_plain
 
     tokens_per_step = cfg["micro_batch"] * cfg["seq_length"] * world
     value = tokens_per_step * a.steps / dt
@@ -266,7 +277,7 @@ def main():
             "model_tflops_per_gpu": round(flops_step * a.steps / dt / 1e12, 1),
             "loss_first_last": [round(losses[0], 4) if losses else None, round(losses[-1], 4)],
             "launch": ("hipGraph replay of the captured step (forward + backward%s), %d timed steps; the same %d steps with eager "
-                       "launches: %.3f ms/step (the roofline kernel's HIP events are recorded in those)"
+                       "launches on one stream: %.3f ms/step (the roofline kernel's HIP events are recorded in those)"
                        % (" + clip + Adam" if world == 1 else "; all-reduce + clip + Adam follow eagerly", a.steps, a.steps,
                           dt_eager / a.steps * 1e3)) if dt_graph is not None else
                       ("eager launches" + (" (graph capture failed: %s)" % graph_err if graph_err else "")),
