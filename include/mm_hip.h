@@ -161,6 +161,17 @@ int mm_gemm_nt_qkv_rotary(void* C, const void* A, const void* B, const void* bia
 int mm_gemm_tn_splits(int M, int N, int Kp);
 int mm_gemm_tn(void* C, void* a_colsum, float* workspace, const void* A, const void* B, int M, int N, int Kp, int lda,
                int ldb, int ldc, int splits, int dtype, void* stream);
+/* mm_gemm_tn without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers
+ * that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * The split-K slabs live in a 24 MiB file-scope device array inside the library (one copy per GPU, held until the process
+ * ends): splits * (N*Kp + (a_colsum ? N : 0)) must not exceed MM_GEMM_TN_STATIC_MAX_FLOATS (6 Mi fp32), larger requests
+ * return MM_EINVAL.  Same kernels, same fixed summation order, so the result is bit-identical to mm_gemm_tn with the same
+ * `splits`.  Every call on one GPU shares that GPU's array: calls that overlap in time on one GPU (two streams) race;
+ * calls on one stream are ordered.  The array's address is resolved on the first call on each device (hipGetSymbolAddress,
+ * no allocation); make that first call outside a graph capture. */
+#define MM_GEMM_TN_STATIC_MAX_FLOATS ((size_t)6 << 20)
+int mm_gemm_tn_static(void* C, void* a_colsum, const void* A, const void* B, int M, int N, int Kp, int lda, int ldb, int ldc,
+                      int splits, int dtype, void* stream);
 /* Two weight gradients over the same M tokens in one launch pair (a linear pair such as the adapter's has two small
  * ones: together they fill the chip).  Contiguous operands (lda = N, ldb = ldc = Kp).  workspace: fp32
  * [splits, N0*Kp0 + N0 + N1*Kp1 + N1] with splits = mm_gemm_tn_pair_splits(...) (0 = not a supported shape). */

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmm_hip.so")
 
 MM_BF16, MM_F16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GELU_ERF, EPI_BIAS_RELU = 0, 1, 2, 3, 4
+GEMM_TN_STATIC_MAX_FLOATS = 6 << 20  # MM_GEMM_TN_STATIC_MAX_FLOATS
 EPI_RELU_BWD, EPI_GELU_TANH_BWD, EPI_GELU_ERF_BWD = 5, 6, 7   # backward epilogues: saved forward tensor in the residual slot
 
 c_int, c_float, c_void_p, c_size_t, c_u64 = (
@@ -51,6 +52,7 @@ PROTOTYPES = {
     "mm_gemm_tn_pair_splits": (c_int, [c_int] * 5),
     "mm_gemm_tn_pair": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] + [c_int] * 2 + [c_void_p]),
     "mm_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "mm_gemm_tn_static": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "mm_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mm_attn_bwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
     "mm_attn_bwd_rotary": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -17,6 +17,7 @@
 // column of that product is the column sum), so the separate column-sum kernels and their pass over dY disappear.
 #include "common.h"
 #include "mfma32.h"
+#include <mutex>
 
 namespace mm {
 
@@ -287,5 +288,57 @@ extern "C" int mm_gemm_tn_pair(void* C0, void* a_colsum0, const void* A0, const 
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
         return tn_launch<T>(p0, p1, workspace, slab, M, splits, (hipStream_t)stream);
+    });
+}
+
+// ---------------------------------------------------------------- the entry point that allocates nothing
+// mm_gemm_tn with its split-K slabs in a file-scope device array instead of a caller workspace, for callers that cannot
+// allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc).  `scratch` below is a host-side stand-in
+// for the symbol, not a device address: host code only ever uses the per-device pointer hipGetSymbolAddress returned.
+constexpr size_t TN_SCRATCH_FLOATS = MM_GEMM_TN_STATIC_MAX_FLOATS;  // 24 MiB per GPU, held until the process ends
+static __device__ __align__(256) float scratch[TN_SCRATCH_FLOATS];
+
+constexpr int TN_MAX_DEVICES = 64;
+static float* g_scratch_ptr[TN_MAX_DEVICES];  // each GPU holds its own copy of the array at its own address
+static std::mutex g_scratch_mu;
+
+// per-device address of `scratch`, resolved on the first call on that device (with that device current)
+static int tn_scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= TN_MAX_DEVICES) {
+        mm::set_error("mm_gemm_tn_static: hipGetDevice failed or device index %d out of range: %s", dev, hipGetErrorString(e));
+        return MM_ELAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        float* ptr = nullptr;
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            mm::set_error("mm_gemm_tn_static: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+            return MM_ELAUNCH;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return MM_OK;
+}
+
+extern "C" int mm_gemm_tn_static(void* C, void* a_colsum, const void* A, const void* B, int M, int N, int Kp, int lda, int ldb,
+                                 int ldc, int splits, int dtype, void* stream) {
+    if (int rc = tn_check("mm_gemm_tn_static", C, a_colsum, A, B, M, N, Kp, lda, ldb, ldc, splits)) return rc;
+    const size_t slab = (size_t)N * Kp + (a_colsum ? N : 0);
+    MM_CHECK_ARG(splits == 1 || slab * (size_t)splits <= TN_SCRATCH_FLOATS,
+                 "mm_gemm_tn_static: splits * (N*Kp + N) = %zu fp32 exceeds the built-in scratch of %zu fp32 (24 MiB): lower "
+                 "`splits` or call mm_gemm_tn with a workspace", slab * (size_t)splits, TN_SCRATCH_FLOATS);
+    float* ws = nullptr;
+    if (splits > 1)  // every slab word the reduction reads is written by this call's first kernel: nothing to clear
+        if (int rc = tn_scratch_for_current_device(&ws)) return rc;
+    const TnProb p0 = tn_prob(C, a_colsum, A, B, N, Kp, lda, ldb, ldc, 0);
+    TnProb p1 = p0;
+    p1.tiles = 0;
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        return tn_launch<T>(p0, p1, ws, slab, M, splits, (hipStream_t)stream);
     });
 }
