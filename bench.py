@@ -37,26 +37,35 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="magma_pythia_410M")
+    ap.add_argument("--tp", type=int, default=1, help="tensor-parallel degree (TP ranks innermost, mpu/initialize.py); DP = gpus / tp")
+    ap.add_argument("--layers", type=int, default=0, help="REHEARSAL ONLY: override num_layers (the JSON line says so; not a valid bench number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches only (no HIP-graph replay)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
 
 
-def roofline_from_probe(cfg, probe):
+def roofline_from_probe(cfg, probe, tp=1):
     """Dominant kernel = the h->4h GEMM with the fused bias-GeLU epilogue (one launch per layer forward).  Its launches
     inside the TIMED steps were bracketed by HIP events on the launch stream (ops.GEMM_EVENT_PROBE); average them."""
+    from multimodal_amd import ops
     T = cfg["micro_batch"] * cfg["seq_length"]
     h = cfg["hidden_size"]
-    ms = sorted(a.elapsed_time(b) for a, b, M, N, K in probe["events"] if (M, N, K) == (T, 4 * h, h))
+    N = 4 * h // tp
+    ms = sorted(a.elapsed_time(b) for a, b, M, Nn, K in probe["events"] if (M, Nn, K) == (T, N, h))
+    if not ms:
+        raise RuntimeError("bench.py: no launch of the roofline kernel (M=%d N=%d K=%d, epilogue %d) was seen by the event probe"
+                           % (T, N, h, probe["epilogue"]))
     avg_ms = sum(ms) / len(ms)
-    flops = 2.0 * T * h * (4 * h)
+    flops = 2.0 * T * h * N
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_nt_256_k<bf16, bias_gelu> M=%d N=%d K=%d" % (T, 4 * h, h),
+    label = "%s<bf16, %s> M=%d N=%d K=%d" % (ops.gemm_nt_kernel_name(T, N, h, probe["epilogue"]),
+                                               "bias_gelu" if cfg["bias_gelu_fusion"] else "bias_gelu_erf", T, N, h)
+    return {"bound": "mfma", "kernel": label,
             "achieved": round(achieved, 2), "peak": PEAK_BF16_FLOPS / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), "avg_kernel_ms": round(avg_ms, 4),
             "median_kernel_ms": round(ms[len(ms) // 2], 4), "launches_timed": len(ms), "flops_per_launch": flops,
-            "traffic": pmc_traffic("gemm_nt_256_k<bf16, bias_gelu> M=%d N=%d K=%d" % (T, 4 * h, h))}
+            "traffic": pmc_traffic(label)}
 
 
 def pmc_traffic(kernel):
@@ -136,10 +145,15 @@ def main():
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
-    mpu.initialize_model_parallel(1)
+    if a.tp < 1 or world % a.tp:
+        raise SystemExit("bench.py: --tp %d does not divide the %d ranks" % (a.tp, world))
+    mpu.initialize_model_parallel(a.tp)  # TP ranks adjacent (innermost), DP groups stride tp: mpu/initialize.py
     mpu.model_parallel_cuda_manual_seed(1234)
-    cfg = harness.CONFIGS[a.config]
-    torch.manual_seed(1234 + rank)
+    cfg = dict(harness.CONFIGS[a.config])
+    if a.layers:
+        cfg["num_layers"] = a.layers
+    dp_rank, dp_world = mpu.get_data_parallel_rank(), world // a.tp
+    torch.manual_seed(1234)  # every replica starts from the same weights (synthetic init; sharded weights repeat across TP ranks)
 
     model = harness.MagmaStack(cfg, dtype=torch.bfloat16, device=device)
     model.train()
@@ -148,7 +162,7 @@ def main():
     # gradient_clipping: 1.0 (magma_pythia_410M.yml:57), megatron/training.py:571-580
     from multimodal_amd.optim import FusedAdam
     opt = FusedAdam(params, lr=8e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
-    batches = [harness.synthetic_batch(cfg, device, seed=1000 * rank + i) for i in range(4)]
+    batches = [harness.synthetic_batch(cfg, device, seed=1000 * dp_rank + i) for i in range(4)]  # one batch per TP group
     dp_group = mpu.get_data_parallel_group()
 
     # static input buffers: the captured graph reads these addresses; each step copies its synthetic batch in first
@@ -163,6 +177,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = model(*static)
         loss.backward()
+        harness.end_of_step()  # device-resident dropout counters move on: a replayed step draws fresh masks
         return loss
 
     def reduce_and_update():
@@ -194,7 +209,9 @@ def main():
     # Replay reproduces the eager step bit for bit (tests/test_graph_gpu.py); it removes the host's per-launch cost (~650
     # launches per step) from the critical path.
     graph, graph_loss, graph_err = None, None, None
-    if not a.no_graph:
+    if a.tp > 1:
+        graph_err = "tensor-parallel step: the RCCL all-reduces inside the layers stay outside graph capture"
+    elif not a.no_graph:
         try:
             load_batch(0)
             graph = torch.cuda.CUDAGraph()
@@ -254,13 +271,14 @@ def main():
     losses.append(float(loss.detach()))
     dt = dt_graph if dt_graph is not None else dt_plain
 
-    tokens_per_step = cfg["micro_batch"] * cfg["seq_length"] * world
+    tokens_per_step = cfg["micro_batch"] * cfg["seq_length"] * dp_world  # a TP group works on ONE micro-batch
     value = tokens_per_step * a.steps / dt
-    flops_step = harness.model_flops_per_step(cfg)
-    mfma_util = flops_step * a.steps / dt / PEAK_BF16_FLOPS  # per GPU (weak scaling: every rank does flops_step)
+    flops_step = harness.model_flops_per_step(cfg) / a.tp   # per GPU (weak scaling over DP; TP splits a replica's work)
+    flops_causal = harness.model_flops_per_step(cfg, causal_exact=True) / a.tp
+    mfma_util = flops_step * a.steps / dt / PEAK_BF16_FLOPS
 
     if rank == 0:
-        roof = roofline_from_probe(cfg, probe)
+        roof = roofline_from_probe(cfg, probe, a.tp)
         out = {
             "metric": "train tokens/sec (node) %s" % a.config, "value": round(value, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -272,8 +290,11 @@ def main():
                                       ("%d image-prefix token + text" % cfg["prefix_len"]) if cfg["prefix_len"] else "text only",
                                       ("adapters r=h/%d trainable, LM frozen" % cfg["adapter_downsample_factor"])
                                       if (cfg["add_adapters"] and cfg["freeze_lm"]) else "all parameters trainable"),
-                       "global_batch": cfg["micro_batch"] * world, "seq_len": cfg["seq_length"], "parallelism": "dp%d" % world},
+                       "global_batch": cfg["micro_batch"] * dp_world, "seq_len": cfg["seq_length"],
+                       "parallelism": ("tp%d x dp%d" % (a.tp, dp_world)) if a.tp > 1 else "dp%d" % world},
             "mfma_util_model": round(mfma_util, 4),
+            "mfma_util_convention": "useful FLOPs / (time x 2.5 PF); attention counted at the full s x s (Megatron convention, "
+                                    "SURVEY 8d); causal-exact (half the attention FLOPs): %.4f" % (flops_causal * a.steps / dt / PEAK_BF16_FLOPS),
             "model_tflops_per_gpu": round(flops_step * a.steps / dt / 1e12, 1),
             "loss_first_last": [round(losses[0], 4) if losses else None, round(losses[-1], 4)],
             "launch": ("hipGraph replay of the captured step (forward + backward%s), %d timed steps; the same %d steps with eager "
@@ -284,6 +305,8 @@ def main():
             "eager_ms_per_step": round(dt_eager / a.steps * 1e3, 3),
             "roofline": roof,
         }
+        if a.layers:
+            out["rehearsal"] = "num_layers overridden to %d: NOT a valid bench number" % a.layers
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)

@@ -94,6 +94,15 @@ int mm_bias_gelu_bwd(void* dy, const void* g, const void* y, const void* bias, i
 int mm_bias_dropout_add(void* out, const void* x, const void* bias, const void* residual,
                         uint8_t* keep_mask, int rows, int cols, float p, int training,
                         uint64_t seed, uint64_t offset, int dtype, void* stream);
+/* mm_bias_dropout_add with the Philox state in DEVICE memory: rng_state = uint64[2] {seed, base offset}; the mask is drawn
+ * from (seed, base offset + offset).  A step captured in a HIP graph bakes `offset` (the call's position within the step) into
+ * the launch but reads the base at run time, and mm_rng_advance (base offset += n, captured at the end of the step) moves it,
+ * so every replay draws fresh masks - the training semantics of the reference's rng tracker (megatron/mpu/random.py:18-37,
+ * DeepSpeed's CudaRNGStatesTracker advancing the generator state).  Same results as mm_bias_dropout_add(seed, base + offset). */
+int mm_bias_dropout_add_devrng(void* out, const void* x, const void* bias, const void* residual, uint8_t* keep_mask,
+                               int rows, int cols, float p, int training, const uint64_t* rng_state, uint64_t offset,
+                               int dtype, void* stream);
+int mm_rng_advance(uint64_t* rng_state, uint64_t n, void* stream);
 /* Column sums: out[cols] (dtype) = sum_rows x[rows, cols] (bias gradients). partial: fp32 [mm_colsum_nblk(rows), cols]. */
 int mm_colsum_nblk(int rows);
 int mm_colsum(void* out, float* partial, const void* x, int rows, int cols, int dtype, void* stream);
@@ -139,6 +148,10 @@ enum {
 /* residual (optional, [M, N] with leading dimension ldc, may alias C): C = round(epilogue(...)) + residual. */
 int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual,
                int M, int N, int K, int lda, int ldb, int ldc, int epilogue, int dtype, void* stream);
+
+/* Host-only: name of the kernel mm_gemm_nt dispatches for a contiguous (lda = ldb = K), 16-byte aligned problem of this shape
+ * ("gemm_nt_256_k", "gemm_nt_128_k" or "gemm_nt_generic_k") - so that a profile row can be matched to a call. */
+const char* mm_gemm_nt_kernel_name(int M, int N, int K, int epilogue);
 
 /* The QKV projection with the rotary embedding as its epilogue: C = rotary(A B^T + bias) - ColumnParallelLinear
  * query_key_value followed by apply_rotary_pos_emb on the q and k slices (megatron/model/transformer.py:552-596,
@@ -264,12 +277,14 @@ int mm_embed_prefix(void* out, const void* table, const int64_t* tokens, const v
  *   chunks : DEVICE array [nchunks] of {int32 tensor, int32 count, int64 tensor_offset, int64 flat_offset}, one per block,
  *            count <= mm_adam_chunk_elems(), tensor_offset and flat_offset multiples of 8 elements;
  *   partial : fp32 [nchunks] workspace; step : device int32, incremented by the call (bias correction uses the new value);
- *   grad_norm_out : optional device float, receives the pre-clip global L2 norm; max_grad_norm <= 0 disables clipping.
+ *   grad_norm_out : optional device float, receives the pre-clip global L2 norm; max_grad_norm <= 0 disables clipping;
+ *   lr_dev : optional device float; when non-NULL the learning rate is read from it at run time and `lr` is ignored (a step
+ *            captured in a HIP graph then follows a scheduler that rewrites the device value between replays).
  * Deterministic (no float atomics); no allocation, no sync. */
 int mm_adam_chunk_elems(void);
 int mm_adam_step(void* const* params, const void* const* grads, float* master, float* exp_avg, float* exp_avg_sq,
-                 const void* chunks, int nchunks, float* partial, int* step, float* grad_norm_out, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, float max_grad_norm, int bias_correction, int dtype, void* stream);
+                 const void* chunks, int nchunks, float* partial, int* step, float* grad_norm_out, float lr,
+                 const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, int bias_correction, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ test-only hardware probe
  * One wave reads a [16][64] 16-bit LDS tile with ds_read_b64_tr_b16; out: [64 lanes][4].  No reference counterpart. */

@@ -36,6 +36,8 @@ PROTOTYPES = {
     "mm_bias_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mm_bias_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mm_bias_dropout_add": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_int, c_u64, c_u64, c_int, c_void_p]),
+    "mm_bias_dropout_add_devrng": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_int, c_void_p, c_u64, c_int, c_void_p]),
+    "mm_rng_advance": (c_int, [c_void_p, c_u64, c_void_p]),
     "mm_colsum_nblk": (c_int, [c_int]),
     "mm_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_transpose2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -43,6 +45,7 @@ PROTOTYPES = {
     "mm_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "mm_gptj_combine": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
     "mm_gemm_nt": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
+    "mm_gemm_nt_kernel_name": (ctypes.c_char_p, [c_int, c_int, c_int, c_int]),
     "mm_gemm_nt_qkv_rotary": (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
     "mm_gemm_tn_splits": (c_int, [c_int, c_int, c_int]),
     "mm_adapter_supported": (c_int, [c_int, c_int]),
@@ -62,7 +65,7 @@ PROTOTYPES = {
     "mm_cross_entropy_fwd_grad_max_v": (c_int, []),
     "mm_embed_prefix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "mm_adam_chunk_elems": (c_int, []),
-    "mm_adam_step": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p] + [c_float] * 6 + [c_int, c_int, c_void_p]),
+    "mm_adam_step": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p] + [c_float] * 5 + [c_int, c_int, c_void_p]),
     "mm_debug_probe_tr_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -189,7 +189,11 @@ def _wrap_keys(module, sd):
     return out
 
 
-def load_checkpoint(model, load_dir, iteration=None, strict=False, finetune=False):
+def optimizer_file(ckpt_dir, mp_rank):
+    return os.path.join(ckpt_dir, "mm_fused_adam_mp_rank_%02d_optim_states.pt" % mp_rank)
+
+
+def load_checkpoint(model, load_dir, iteration=None, strict=False, finetune=False, optimizer=None):
     """Load the language-model / adapter / image-prefix weights of a DeepSpeed-format NeoX checkpoint into a
     `harness.MagmaStack`, resharding from the checkpoint's tensor-parallel degree to the running one.
 
@@ -251,10 +255,22 @@ def load_checkpoint(model, load_dir, iteration=None, strict=False, finetune=Fals
             if m is None:
                 raise ValueError("Unable to load iteration from checkpoint %s" % ckpt_dir)
             it = int(m.group(1))
-    return int(it), dict(missing=missing, unexpected=unexpected, client_state=client, tag=tag)
+    opt_loaded = False
+    if optimizer is not None:
+        # The reference builds the optimizer BEFORE load_checkpoint (megatron/training.py:646,690) and lets the DeepSpeed
+        # engine restore / refresh its fp32 masters.  Here: restore FusedAdam's state when this library saved one next to the
+        # layer files (same TP degree only: the flat state is per-rank), else re-derive the fp32 master copy from the weights
+        # just loaded - without either the first opt.step() would write the stale master back over them.
+        of = optimizer_file(ckpt_dir, rank)
+        if not finetune and parts == world and os.path.isfile(of):
+            optimizer.load_state_dict(_safe_load(of))
+            opt_loaded = True
+        else:
+            optimizer.refresh_master_from_params()
+    return int(it), dict(missing=missing, unexpected=unexpected, client_state=client, tag=tag, optimizer_state_loaded=opt_loaded)
 
 
-def save_checkpoint(model, save_dir, iteration, client_state=None):
+def save_checkpoint(model, save_dir, iteration, client_state=None, optimizer=None):
     """Write this rank's tensor-parallel partition in the pipeline layout above (checkpointing.py:165-205; one caller
     per TP rank, data-parallel rank 0 only) and point `latest` at it."""
     tag = "global_step%d" % iteration
@@ -272,6 +288,10 @@ def save_checkpoint(model, save_dir, iteration, client_state=None):
     state["iteration"] = int(iteration)
     state["module"] = None  # PipelineModule keeps the weights in the layer files
     torch.save(state, client_file(ckpt_dir, rank))
+    if optimizer is not None:  # step, fp32 master, moments (plain tensors and numbers: readable with weights_only=True)
+        sd = optimizer.state_dict()
+        sd["master"], sd["exp_avg"], sd["exp_avg_sq"] = (sd[k].to("cpu") for k in ("master", "exp_avg", "exp_avg_sq"))
+        torch.save(sd, optimizer_file(ckpt_dir, rank))
     if rank == 0:
         with open(os.path.join(save_dir, "latest"), "w") as f:
             f.write(tag)

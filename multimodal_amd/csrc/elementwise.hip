@@ -119,7 +119,11 @@ template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void bias_dropout_add_k(u16* __restrict__ out, const u16* __restrict__ x,
                                                           const u16* __restrict__ bias, const u16* __restrict__ res,
                                                           uint8_t* __restrict__ keep, size_t rows, int cols, float p,
-                                                          uint64_t seed, uint64_t offset) {
+                                                          uint64_t seed, uint64_t offset, const uint64_t* __restrict__ rng_state) {
+    if (DROP && rng_state) {  // device-resident Philox state {seed, base offset}: a replayed HIP graph draws a fresh mask
+        seed = rng_state[0];
+        offset += rng_state[1];
+    }
     const int cpr = cols >> 3;
     const size_t total = rows * cpr;
     const float inv_keep = DROP ? 1.0f / (1.0f - p) : 1.0f;
@@ -283,9 +287,38 @@ extern "C" int mm_bias_gelu_bwd(void* dy, const void* g, const void* y, const vo
     });
 }
 
+// state[1] += n, one lane (vector store)
+__global__ void rng_advance_k(uint64_t* __restrict__ state, uint64_t n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += n;
+}
+
+static int bias_dropout_add_impl(void* out, const void* x, const void* bias, const void* residual, uint8_t* keep_mask,
+                                 int rows, int cols, float p, int training, uint64_t seed, uint64_t offset,
+                                 const uint64_t* rng_state, int dtype, void* stream);
+
 extern "C" int mm_bias_dropout_add(void* out, const void* x, const void* bias, const void* residual, uint8_t* keep_mask,
                                    int rows, int cols, float p, int training, uint64_t seed, uint64_t offset, int dtype,
                                    void* stream) {
+    return bias_dropout_add_impl(out, x, bias, residual, keep_mask, rows, cols, p, training, seed, offset, nullptr, dtype, stream);
+}
+
+extern "C" int mm_bias_dropout_add_devrng(void* out, const void* x, const void* bias, const void* residual, uint8_t* keep_mask,
+                                          int rows, int cols, float p, int training, const uint64_t* rng_state,
+                                          uint64_t offset, int dtype, void* stream) {
+    MM_CHECK_ARG(rng_state && (((uintptr_t)rng_state) & 7) == 0, "mm_bias_dropout_add_devrng: rng_state must be an 8-byte aligned device uint64[2]");
+    return bias_dropout_add_impl(out, x, bias, residual, keep_mask, rows, cols, p, training, 0, offset, rng_state, dtype, stream);
+}
+
+extern "C" int mm_rng_advance(uint64_t* rng_state, uint64_t n, void* stream) {
+    MM_CHECK_ARG(rng_state && (((uintptr_t)rng_state) & 7) == 0, "mm_rng_advance: rng_state must be an 8-byte aligned device uint64[2]");
+    rng_advance_k<<<1, 64, 0, (hipStream_t)stream>>>(rng_state, n);
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
+static int bias_dropout_add_impl(void* out, const void* x, const void* bias, const void* residual, uint8_t* keep_mask,
+                                 int rows, int cols, float p, int training, uint64_t seed, uint64_t offset,
+                                 const uint64_t* rng_state, int dtype, void* stream) {
     MM_CHECK_ARG(out && x, "mm_bias_dropout_add: null pointer");
     MM_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0, "mm_bias_dropout_add: rows=%d cols=%d (cols must be a multiple of 8)", rows, cols);
     MM_CHECK_ARG(p >= 0.f && p < 1.f, "mm_bias_dropout_add: dropout probability %f out of [0,1)", (double)p);
@@ -297,10 +330,10 @@ extern "C" int mm_bias_dropout_add(void* out, const void* x, const void* bias, c
         using T = decltype(t);
         if (drop)
             bias_dropout_add_k<T, true><<<grid_for(items), 256, 0, (hipStream_t)stream>>>((u16*)out, (const u16*)x, (const u16*)bias,
-                                                                                        (const u16*)residual, keep_mask, rows, cols, p, seed, offset);
+                                                                                        (const u16*)residual, keep_mask, rows, cols, p, seed, offset, rng_state);
         else
             bias_dropout_add_k<T, false><<<grid_for(items), 256, 0, (hipStream_t)stream>>>((u16*)out, (const u16*)x, (const u16*)bias,
-                                                                                         (const u16*)residual, nullptr, rows, cols, p, seed, offset);
+                                                                                         (const u16*)residual, nullptr, rows, cols, p, seed, offset, nullptr);
         MM_CHECK_LAUNCH();
         return (int)MM_OK;
     });

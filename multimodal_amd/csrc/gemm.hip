@@ -223,6 +223,13 @@ extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, cons
     });
 }
 
+extern "C" const char* mm_gemm_nt_kernel_name(int M, int N, int K, int epilogue) {
+    (void)epilogue;
+    if (M <= 0 || N <= 0 || K <= 0) return "none";
+    if (K % 64 || N % 4) return "gemm_nt_generic_k";
+    return gemm256_takes(M, N, K, K, K) ? "gemm_nt_256_k" : "gemm_nt_128_k";
+}
+
 extern "C" int mm_gemm_nt_qkv_rotary(void* C, const void* A, const void* B, const void* bias, const void* cos, const void* sin,
                                      int M, int N, int K, int lda, int ldb, int ldc, int b, int hn, int d, int offset, int dtype,
                                      void* stream) {

@@ -214,15 +214,20 @@ static int launch256_epi(void* C, void* aux, const void* A, const void* B, const
 // partial last one does not matter); otherwise the 128x128 kernel with ~3 workgroups per CU balances better.  Measured at
 // M = 8192 (TFLOP/s, this kernel vs gemm.hip): N=4096 K=1024 1058 vs 879, N=50432 K=1024 999 vs 810, N=3072 (1.5 rounds) 791 vs 807,
 // N=1024 (half a round) 690 vs 990.
-int gemm256_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
-                int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st, const EpiExtra& ex) {
+bool gemm256_takes(int M, int N, int K, int lda, int ldb) {
     int force = 0;
     if (const char* e = getenv("MM_GEMM256")) force = atoi(e);  // developer switch: 1 = always (when legal), -1 = never
-    if (force < 0 || M < 256 || N < 256 || K < 128) return 1;
+    if (force < 0 || M < 256 || N < 256 || K < 128) return false;
     // staging uses 32-bit byte offsets from the operand base
-    if ((size_t)M * (size_t)lda * 2 >= (1ull << 32) || (size_t)N * (size_t)ldb * 2 >= (1ull << 32)) return 1;
+    if ((size_t)M * (size_t)lda * 2 >= (1ull << 32) || (size_t)N * (size_t)ldb * 2 >= (1ull << 32)) return false;
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-    if (force == 0 && !(tiles % 256 == 0 || tiles >= 1024)) return 1;
+    if (force == 0 && !(tiles % 256 == 0 || tiles >= 1024)) return false;
+    return true;
+}
+
+int gemm256_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
+                int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st, const EpiExtra& ex) {
+    if (!gemm256_takes(M, N, K, lda, ldb)) return 1;
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
         return launch256_epi<T>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, st, ex);

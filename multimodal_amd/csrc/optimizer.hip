@@ -68,10 +68,10 @@ __global__ __launch_bounds__(256) void adam_update_k(u16* const* __restrict__ pa
                                                      float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                      float* __restrict__ grad_norm_out, const float* __restrict__ partial,
                                                      int nchunks, const int* __restrict__ step, const AdamChunk* __restrict__ chunks,
-                                                     const u16* const* __restrict__ grads, float lr, float b1, float b2, float eps,
-                                                     float wd, float max_norm, int bias_correction) {
+                                                     const u16* const* __restrict__ grads, float lr, const float* __restrict__ lr_dev,
+                                                     float b1, float b2, float eps, float wd, float max_norm, int bias_correction) {
     __shared__ float red[4];
-    __shared__ float sh[3];
+    __shared__ float sh[4];
     // global norm: every block adds the same partials in the same order
     float acc = 0.f;
     for (int i = threadIdx.x; i < nchunks; i += 256) acc += partial[i];
@@ -89,10 +89,12 @@ __global__ __launch_bounds__(256) void adam_update_k(u16* const* __restrict__ pa
         sh[0] = clip;
         sh[1] = (float)(1.0 / bc1);
         sh[2] = (float)(1.0 / sqrt(bc2));
+        sh[3] = lr_dev ? *lr_dev : lr;  // device-resident learning rate: a scheduler's value reaches a replayed HIP graph
         if (blockIdx.x == 0 && grad_norm_out) *grad_norm_out = norm;
     }
     __syncthreads();
     const float clip = sh[0], inv_bc1 = sh[1], inv_sqrt_bc2 = sh[2];
+    lr = sh[3];
     const AdamChunk c = chunks[blockIdx.x];
     const u16* g = grads[c.tensor];
     if (g == nullptr) return;  // a parameter without a gradient this step is left alone (torch / apex semantics)
@@ -161,7 +163,7 @@ extern "C" int mm_adam_chunk_elems(void) { return OPT_CHUNK; }
 
 extern "C" int mm_adam_step(void* const* params, const void* const* grads, float* master, float* exp_avg, float* exp_avg_sq,
                             const void* chunks, int nchunks, float* partial, int* step, float* grad_norm_out, float lr,
-                            float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, int bias_correction,
+                            const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, int bias_correction,
                             int dtype, void* stream) {
     MM_CHECK_ARG(params && grads && master && exp_avg && exp_avg_sq && chunks && partial && step, "mm_adam_step: null pointer");
     MM_CHECK_ARG(nchunks > 0, "mm_adam_step: nchunks=%d must be positive", nchunks);
@@ -175,7 +177,7 @@ extern "C" int mm_adam_step(void* const* params, const void* const* grads, float
         adam_sqnorm_k<T><<<nchunks, 256, 0, st>>>(partial, step, (const AdamChunk*)chunks, (const u16* const*)grads);
         MM_CHECK_LAUNCH();
         adam_update_k<T><<<nchunks, 256, 0, st>>>((u16* const*)params, master, exp_avg, exp_avg_sq, grad_norm_out, partial, nchunks,
-                                                  step, (const AdamChunk*)chunks, (const u16* const*)grads, lr, beta1, beta2, eps,
+                                                  step, (const AdamChunk*)chunks, (const u16* const*)grads, lr, lr_dev, beta1, beta2, eps,
                                                   weight_decay, max_grad_norm, bias_correction);
         MM_CHECK_LAUNCH();
         return (int)MM_OK;

@@ -353,10 +353,10 @@ class BiasDropoutAddFn(torch.autograd.Function):
     """bias_dropout_add (megatron/model/fused_bias_dropout.py:28-34)."""
 
     @staticmethod
-    def forward(ctx, x, bias, residual, p, training, seed, offset):
+    def forward(ctx, x, bias, residual, p, training, seed, offset, rng_state=None):
         drop = training and p > 0
         if drop:
-            out, keep = ops.bias_dropout_add(x, bias, residual, p, True, seed, offset, want_mask=True)
+            out, keep = ops.bias_dropout_add(x, bias, residual, p, True, seed, offset, want_mask=True, rng_state=rng_state)
             ctx.save_for_backward(keep)
         else:
             out = ops.bias_dropout_add(x, bias, residual, 0.0, training)
@@ -373,16 +373,18 @@ class BiasDropoutAddFn(torch.autograd.Function):
             dx = (g * keep.to(g.dtype)) * (1.0 / (1.0 - ctx.p))  # rare path (every listed config has p = 0)
         db = ops.colsum(_flat2d(dx)) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         dres = g if (ctx.has_res and ctx.needs_input_grad[2]) else None
-        return dx, db, dres, None, None, None, None
+        return dx, db, dres, None, None, None, None, None
 
 
-def bias_dropout_add(x, bias, residual, prob, training, seed=0, offset=0):
+def bias_dropout_add(x, bias, residual, prob, training, seed=0, offset=0, rng_state=None):
     """bias may be a [cols] vector or its expand_as view (the reference passes `bias.expand_as(x)`)."""
     if bias is not None and bias.dim() > 1:
-        bias = bias.reshape(-1, bias.size(-1))[0] if bias.stride(-1) == 1 and all(st == 0 for st in bias.stride()[:-1]) else bias
+        # an expanded view repeats one row: every leading dimension has stride 0 (or size 1, whose stride is arbitrary)
+        lead_ok = all(st == 0 or n == 1 for st, n in zip(bias.stride()[:-1], bias.shape[:-1]))
+        bias = bias.reshape(-1, bias.size(-1))[0] if bias.stride(-1) == 1 and lead_ok else bias
         if bias.dim() > 1:
             raise RuntimeError("bias_dropout_add: bias must be a vector (or an expanded view of one)")
-    return BiasDropoutAddFn.apply(x, bias, residual, float(prob), bool(training), int(seed), int(offset))
+    return BiasDropoutAddFn.apply(x, bias, residual, float(prob), bool(training), int(seed), int(offset), rng_state)
 
 
 class GptjCombineFn(torch.autograd.Function):

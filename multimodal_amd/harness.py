@@ -34,6 +34,25 @@ CONFIGS = {
                                  gpt_j_residual=True, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
                                  add_adapters=True, adapter_downsample_factor=8, freeze_lm=True, micro_batch=4,
                                  padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1),
+    # configs/summit-1-3B.yml:5-33 - BASELINE.json configs[3] runs it at tensor-parallel 2 x data-parallel 4 (the YAML's own
+    # model-parallel-size 3 / pipe 2 is a Summit layout; 18 heads % 2 == 0 and 2304 % 2 == 0 satisfy transformer.py:210-217).
+    # No adapters, LM trainable, image prefix on (openclip-H -> 1 prefix token)
+    "summit-1-3B": dict(hidden_size=2304, num_attention_heads=18, num_layers=24, seq_length=2048, rotary_pct=1.0,
+                        gpt_j_residual=False, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
+                        add_adapters=False, adapter_downsample_factor=8, freeze_lm=False, micro_batch=4,
+                        padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1),
+    # configs/6-7B.yml:5-22 shape as a multimodal model (BASELINE.json configs[4]: tensor-parallel 8): image prefix as in the
+    # other multimodal configs, LM trainable
+    "6-7B": dict(hidden_size=4096, num_attention_heads=32, num_layers=32, seq_length=2048, rotary_pct=1.0,
+                 gpt_j_residual=False, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
+                 add_adapters=False, adapter_downsample_factor=8, freeze_lm=False, micro_batch=4,
+                 padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1),
+    # a small MAGMA stack with everything the 410M recipe has (adapters of a shape the fused adapter kernel takes, frozen LM,
+    # image prefix with dropout): what tests/test_graph_gpu.py captures
+    "tiny_magma": dict(hidden_size=512, num_attention_heads=8, num_layers=2, seq_length=256, rotary_pct=0.25,
+                       gpt_j_residual=True, bias_gelu_fusion=True, scaled_upper_triang_masked_softmax_fusion=True,
+                       add_adapters=True, adapter_downsample_factor=8, freeze_lm=True, micro_batch=2,
+                       padded_vocab_size=1024, encoder_out_dim=64, prefix_len=1, image_embed_dropout_prob=0.1),
     "tiny": dict(hidden_size=256, num_attention_heads=4, num_layers=2, seq_length=256, rotary_pct=0.25,
                  gpt_j_residual=True, bias_gelu_fusion=True, scaled_upper_triang_masked_softmax_fusion=True,
                  add_adapters=False, adapter_downsample_factor=8, freeze_lm=False, micro_batch=2,
@@ -79,8 +98,8 @@ class ImagePrefixProj(nn.Module):
     def forward(self, enc_out):  # [b, P, enc_dim]
         y = Fn.linear(enc_out, self.proj.weight, self.proj.bias)
         if self.training and self.dropout_p > 0:
-            seed, off = mpu.get_cuda_rng_tracker().draw()
-            y = Fn.bias_dropout_add(y, None, None, self.dropout_p, True, seed, off)
+            state, pos = mpu.get_cuda_rng_tracker().draw_device(y.device)  # fresh mask at every HIP-graph replay too
+            y = Fn.bias_dropout_add(y, None, None, self.dropout_p, True, 0, pos, rng_state=state)
         return self.ln(y)
 
 
@@ -88,7 +107,7 @@ class MagmaStack(nn.Module):
     def __init__(self, cfg, dtype=torch.bfloat16, device="cuda"):
         super().__init__()
         self.cfg = cfg
-        args = neox_args_for(cfg, dtype)
+        args = neox_args_for(cfg, dtype, tp=mpu.get_model_parallel_world_size())
         self.args = args
         h, L, V = cfg["hidden_size"], cfg["num_layers"], cfg["padded_vocab_size"]
         init, out_init = small_init(h), wang_init(L, h)
@@ -147,8 +166,20 @@ class MagmaStack(nn.Module):
         if (self.cfg.get("fused_head_loss", True) and torch.is_grad_enabled() and mpu.get_model_parallel_world_size() == 1
                 and Fn.lm_head_loss_supported(x, w)):
             return Fn.lm_head_loss(x, w, labels, loss_mask)  # head + loss, logits read once
-        logits, _ = self.final_linear(x)
+        logits, _ = self.final_linear(x)  # [b, s, V/p]: gather_output=False (transformer.py:151-161)
+        if mpu.get_model_parallel_world_size() > 1:
+            # vocabulary-parallel loss over the TP group (gpt2_model.py:52-70 -> mpu/cross_entropy.py:27-117): three [b, s]
+            # exchanges; each rank's softmax runs over its own partition only
+            losses = mpu.vocab_parallel_cross_entropy(logits, labels)
+            lm = loss_mask.reshape(-1).float()
+            return torch.sum(losses.reshape(-1) * lm) / lm.sum()
         return Fn.masked_cross_entropy(logits, labels, loss_mask)
+
+
+def end_of_step():
+    """Call once per training step after the backward: moves the device-resident dropout counters past this step's draws
+    (one capturable launch), so that the next step - or the next replay of a captured step - draws fresh masks."""
+    mpu.get_cuda_rng_tracker().commit()
 
 
 def synthetic_batch(cfg, device, seed, dtype=torch.bfloat16):
@@ -166,13 +197,14 @@ def synthetic_batch(cfg, device, seed, dtype=torch.bfloat16):
     return enc, tokens.to(device), tokens.to(device), loss_mask.to(device)
 
 
-def model_flops_per_step(cfg):
+def model_flops_per_step(cfg, causal_exact=False):
     """Useful FLOPs of one micro-batch step under the BASELINE.md section 4 work model (full s x s attention counting,
-    recompute not counted; frozen LM => backward = 1x linear + 2x attention; adapters trainable => 3x)."""
+    recompute not counted; frozen LM => backward = 1x linear + 2x attention; adapters trainable => 3x).
+    causal_exact: count only the unmasked half of the attention products (what the causal kernels execute)."""
     h, L, s, b, V = cfg["hidden_size"], cfg["num_layers"], cfg["seq_length"], cfg["micro_batch"], cfg["padded_vocab_size"]
     T = s * b
     f_lin = 24 * T * h * h
-    f_attn = 4 * T * s * h
+    f_attn = 4 * T * s * h // (2 if causal_exact else 1)
     f_ad = 8 * T * h * (h // cfg["adapter_downsample_factor"]) if cfg["add_adapters"] else 0
     f_head = 2 * T * h * V
     if cfg["freeze_lm"]:

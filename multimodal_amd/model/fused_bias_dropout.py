@@ -4,10 +4,11 @@ from ..mpu.random import get_cuda_rng_tracker
 
 
 def bias_dropout_add(x, bias, residual, prob, training):
-    seed, offset = (0, 0)
     if training and prob > 0:
-        seed, offset = get_cuda_rng_tracker().draw()
-    return Fn.bias_dropout_add(x, bias, residual, prob, training, seed, offset)
+        # device-resident Philox state: the launch carries only its position inside the step (mpu/random.py)
+        state, pos = get_cuda_rng_tracker().draw_device(x.device)
+        return Fn.bias_dropout_add(x, bias, residual, prob, training, 0, pos, rng_state=state)
+    return Fn.bias_dropout_add(x, bias, residual, prob, training)
 
 
 def get_bias_dropout_add(training):

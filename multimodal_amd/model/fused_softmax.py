@@ -1,48 +1,61 @@
-"""FusedScaleMaskSoftmax and its two autograd Functions with the reference's dispatch rules
-(megatron/model/fused_softmax.py:24-205).  The kernels are the HIP ones behind the
-`scaled_*_softmax_cuda` module names (multimodal_amd.fused_kernels)."""
+"""scale + mask + softmax over attention scores: the operator interface of megatron/model/fused_softmax.py:24-205
+(`FusedScaleMaskSoftmax`, `SoftmaxFusionTypes`, the two autograd Functions) on the HIP softmax kernels.
+
+Two drop-in levels exist:
+  level 1 - the reference's OWN fused_softmax.py keeps working unchanged once `multimodal_amd.fused_kernels.
+            load_fused_kernels()` has registered the modules it imports by name;
+  level 2 - this module: same class / method names and the same eligibility rule, calling the C ABI through
+            `multimodal_amd.ops` directly (no import-by-name, the scale stays a Python float).
+Both are exercised by tests/test_fused_kernels_shim_gpu.py.
+"""
 import enum
 
 import torch
 import torch.nn as nn
 
-from ..fused_kernels import load_fused_kernels
+from .. import ops
+
+MAX_FUSED_KEYS = 2048   # the kernels hold one row in registers (scaled_masked_softmax_cuda.cu:44, fused_softmax.py:155)
+
+
+class _InPlaceSoftmaxBackward:
+    """Shared backward contract of both kernels (…_cuda.cu:77-105): the gradient is written over `output_grads`
+    (a contiguous copy of it when it was strided) and that tensor is what autograd receives."""
+
+    @staticmethod
+    def run(kernel, ctx, output_grads):
+        (probs,) = ctx.saved_tensors
+        return kernel(output_grads, probs, ctx.softmax_scale)
 
 
 class ScaledUpperTriangMaskedSoftmax(torch.autograd.Function):
-    """fused_softmax.py:24-53."""
+    """Causal: row r of every [s, s] matrix is softmax(scale * x[r, :r+1]), zeros above the diagonal (fused_softmax.py:24-53)."""
 
     @staticmethod
     def forward(ctx, inputs, scale):
-        import scaled_upper_triang_masked_softmax_cuda
-        scale_t = torch.tensor([scale])
-        softmax_results = scaled_upper_triang_masked_softmax_cuda.forward(inputs, scale_t[0])
-        ctx.save_for_backward(softmax_results, scale_t)
-        return softmax_results
+        ctx.softmax_scale = float(scale)
+        probs = ops.softmax_causal_fwd(inputs, ctx.softmax_scale)
+        ctx.save_for_backward(probs)
+        return probs
 
     @staticmethod
     def backward(ctx, output_grads):
-        import scaled_upper_triang_masked_softmax_cuda
-        softmax_results, scale_t = ctx.saved_tensors
-        return scaled_upper_triang_masked_softmax_cuda.backward(output_grads, softmax_results, scale_t[0]), None
+        return _InPlaceSoftmaxBackward.run(ops.softmax_causal_bwd, ctx, output_grads), None
 
 
 class ScaledMaskedSoftmax(torch.autograd.Function):
-    """fused_softmax.py:56-83."""
+    """Explicit byte mask [1|b, 1, sq, sk], 1 = masked (-10000 fill) (fused_softmax.py:56-83)."""
 
     @staticmethod
     def forward(ctx, inputs, mask, scale):
-        import scaled_masked_softmax_cuda
-        scale_t = torch.tensor([scale])
-        softmax_results = scaled_masked_softmax_cuda.forward(inputs, mask, scale_t[0])
-        ctx.save_for_backward(softmax_results, scale_t)
-        return softmax_results
+        ctx.softmax_scale = float(scale)
+        probs = ops.softmax_masked_fwd(inputs, mask, ctx.softmax_scale)
+        ctx.save_for_backward(probs)
+        return probs
 
     @staticmethod
     def backward(ctx, output_grads):
-        import scaled_masked_softmax_cuda
-        softmax_results, scale_t = ctx.saved_tensors
-        return scaled_masked_softmax_cuda.backward(output_grads, softmax_results, scale_t[0]), None, None
+        return _InPlaceSoftmaxBackward.run(ops.softmax_masked_bwd, ctx, output_grads), None, None
 
 
 class SoftmaxFusionTypes(enum.Enum):
@@ -51,65 +64,71 @@ class SoftmaxFusionTypes(enum.Enum):
     none = 3  # no fusion
 
 
+def fused_kernel_eligible(fusion_type, sixteen_bit, has_mask, b, np, sq, sk):
+    """The reference's availability rule (fused_softmax.py:148-168) as a pure function of the configuration and shape.
+    `batch_per_block` comes from the library (wave64 value, scaled_masked_softmax.h:338-352 with C10_WARP_SIZE = 64)."""
+    if fusion_type == SoftmaxFusionTypes.none or not sixteen_bit or not has_mask:
+        return False
+    if not (16 < sk <= MAX_FUSED_KEYS) or sq % 4 or (b * np) % 4:
+        return False
+    per_block = ops.softmax_batch_per_block(sq, sk, b, np)
+    rows_or_batches = b * np if fusion_type == SoftmaxFusionTypes.upper_triang else sq
+    return rows_or_batches % per_block == 0
+
+
 class FusedScaleMaskSoftmax(nn.Module):
-    """scale + mask + softmax with the reference's eligibility test (fused_softmax.py:92-205).  When the fused kernels
-    do not apply (sk > 2048, odd shapes, fp32) the reference falls back to eager torch ops; so does this class - that
-    branch is the reference's own behaviour, not a substitute for a missing library (load_fused_kernels() raises)."""
+    """Constructor and methods as the reference's (fused_softmax.py:92-205).  Shapes or dtypes the kernels do not take run
+    the reference's own eager sequence (`forward_torch_softmax`, in-place masked_fill through `mask_func`): that branch is
+    reference behaviour, not a stand-in for a missing library - constructing the module with a fusion type loads
+    libmm_hip.so and raises if it is absent."""
 
     def __init__(self, input_in_fp16, input_in_bf16, fusion_type, mask_func, softmax_in_fp32, scale):
         super().__init__()
-        self.input_in_fp16 = input_in_fp16
-        self.input_in_bf16 = input_in_bf16
+        if not isinstance(fusion_type, SoftmaxFusionTypes):
+            raise AssertionError(f"Invalid fusion type {fusion_type}")
+        if scale is not None and not softmax_in_fp32:
+            raise AssertionError("softmax should be in fp32 when scaled")
+        self.input_in_fp16, self.input_in_bf16 = input_in_fp16, input_in_bf16
         self.input_in_float16 = input_in_fp16 or input_in_bf16
-        assert fusion_type in [SoftmaxFusionTypes.upper_triang, SoftmaxFusionTypes.general, SoftmaxFusionTypes.none], \
-            f"Invalid fusion type {fusion_type}"
-        if fusion_type != SoftmaxFusionTypes.none:
-            load_fused_kernels()
+        self.fusion_type = fusion_type
+        self.fusion = fusion_type != SoftmaxFusionTypes.none
         self.upper_triang_mask_fusion = fusion_type == SoftmaxFusionTypes.upper_triang
         self.general_mask_fusion = fusion_type == SoftmaxFusionTypes.general
-        self.fusion = fusion_type != SoftmaxFusionTypes.none
-        self.mask_func = mask_func
-        self.softmax_in_fp32 = softmax_in_fp32
-        self.scale = scale
-        assert self.scale is None or softmax_in_fp32, "softmax should be in fp32 when scaled"
+        self.mask_func, self.softmax_in_fp32, self.scale = mask_func, softmax_in_fp32, scale
+        if self.fusion:
+            from ..fused_kernels import load_fused_kernels
+            load_fused_kernels()
 
     def forward(self, input, mask):
-        assert input.dim() == 4
-        if self.is_kernel_available(mask, *input.size()):
-            return self.forward_fused_softmax(input, mask)
-        return self.forward_torch_softmax(input, mask)
+        if input.dim() != 4:
+            raise AssertionError("expected [b, np, sq, sk] attention scores")
+        fused = self.is_kernel_available(mask, *input.size())
+        return (self.forward_fused_softmax if fused else self.forward_torch_softmax)(input, mask)
 
     def is_kernel_available(self, mask, b, np, sq, sk):
-        attn_batches = b * np
-        if (self.fusion and self.input_in_float16 and mask is not None and 16 < sk <= 2048
-                and sq % 4 == 0 and attn_batches % 4 == 0):
-            batch_per_block = self.get_batch_per_block(sq, sk, b, np)
-            if self.upper_triang_mask_fusion:
-                return attn_batches % batch_per_block == 0
-            return sq % batch_per_block == 0
-        return False
+        return fused_kernel_eligible(self.fusion_type, self.input_in_float16, mask is not None, b, np, sq, sk)
 
     def forward_fused_softmax(self, input, mask):
         b, np, sq, sk = input.size()
-        scale = self.scale if self.scale is not None else 1.0
+        scale = 1.0 if self.scale is None else self.scale
         if self.upper_triang_mask_fusion:
-            assert sq == sk, "causal mask is only for self attention"
-            probs = ScaledUpperTriangMaskedSoftmax.apply(input.view(-1, sq, sk), scale)
-            return probs.view(b, np, sq, sk)
+            if sq != sk:
+                raise AssertionError("causal mask is only for self attention")
+            # the causal kernel masks by position and never reads `mask` (fused_softmax.py:173-179)
+            return ScaledUpperTriangMaskedSoftmax.apply(input.view(b * np, sq, sk), scale).view(b, np, sq, sk)
         return ScaledMaskedSoftmax.apply(input, mask, scale)
 
     def forward_torch_softmax(self, input, mask):
-        if self.input_in_float16 and self.softmax_in_fp32:
-            input = input.float()
+        """fused_softmax.py:184-199: optional fp32 up-cast, scale, mask_func (in place), Softmax, cast back."""
+        upcast = self.input_in_float16 and self.softmax_in_fp32
+        x = input.float() if upcast else input
         if self.scale is not None:
-            input = input * self.scale
-        mask_output = self.mask_func(input, mask) if mask is not None else input
-        probs = torch.nn.Softmax(dim=-1)(mask_output)
-        if self.input_in_float16 and self.softmax_in_fp32:
-            probs = probs.half() if self.input_in_fp16 else probs.bfloat16()
-        return probs
+            x = x * self.scale
+        if mask is not None:
+            x = self.mask_func(x, mask)
+        probs = torch.softmax(x, dim=-1)
+        return probs.to(torch.float16 if self.input_in_fp16 else torch.bfloat16) if upcast else probs
 
     @staticmethod
     def get_batch_per_block(sq, sk, b, np):
-        import scaled_masked_softmax_cuda
-        return scaled_masked_softmax_cuda.get_batch_per_block(sq, sk, b, np)
+        return ops.softmax_batch_per_block(sq, sk, b, np)

@@ -5,6 +5,12 @@ surface (`get_cuda_rng_tracker().fork()`, `model_parallel_cuda_manual_seed`) but
 Philox counter per named stream instead of swapping the device generator state: the HIP dropout kernels
 take (seed, offset) as arguments (include/mm_hip.h, mm_bias_dropout_add), so forking costs nothing and a
 recomputed forward replays exactly when the caller restores the offsets (`get_states` / `set_states`).
+
+Device-resident form (`draw_device` / `commit`): the stream's {seed, base offset} also lives in a device uint64[2] that
+the dropout kernel reads at run time (mm_bias_dropout_add_devrng); a launch only carries its position inside the step.
+`commit()` - one tiny kernel at the end of a training step - moves the base by the number of draws of that step.  A step
+captured in a HIP graph therefore draws FRESH masks at every replay, like the eager step, instead of replaying the
+(seed, offset) integers that were baked into the captured launches.
 """
 import contextlib
 
@@ -19,6 +25,8 @@ class RngStatesTracker:
         self.states_ = {}
         self.active_ = "default"
         self.states_["default"] = [0, 0]
+        self.dev_ = {}      # (name, device) -> uint64[2] device tensor {seed, base offset} (stored as int64)
+        self.pending_ = {}  # (name, device) -> draws since the last commit (host side: positions inside the step)
 
     def add(self, name, seed):
         if name in self.states_:
@@ -26,10 +34,11 @@ class RngStatesTracker:
         self.states_[name] = [int(seed), 0]
 
     def get_states(self):
-        return {k: list(v) for k, v in self.states_.items()}
+        return {"host": {k: list(v) for k, v in self.states_.items()}, "pending": dict(self.pending_)}
 
     def set_states(self, states):
-        self.states_ = {k: list(v) for k, v in states.items()}
+        self.states_ = {k: list(v) for k, v in states["host"].items()}
+        self.pending_ = dict(states["pending"])
 
     @contextlib.contextmanager
     def fork(self, name=_MODEL_PARALLEL_RNG_TRACKER_NAME):
@@ -47,6 +56,33 @@ class RngStatesTracker:
         seed, off = st[0], st[1]
         st[1] += n
         return seed, off
+
+
+    def draw_device(self, device, n=1):
+        """(state tensor, offset within the step) for the next dropout launch on the active stream: the kernel draws from
+        (state[0], state[1] + offset).  The device state is created on first use from the stream's host (seed, offset)."""
+        import torch
+        key = (self.active_, torch.device(device))
+        st = self.dev_.get(key)
+        if st is None:
+            seed, off = self.states_[self.active_]
+            st = self.dev_[key] = torch.tensor([seed, off], dtype=torch.int64, device=device)
+            self.pending_[key] = 0
+        pos = self.pending_[key]
+        self.pending_[key] = pos + n
+        return st, pos
+
+    def commit(self):
+        """End of a training step (after the backward: a recompute replays the step's positions): base offset += draws of
+        this step, on the device (capturable), and the per-step positions restart at 0."""
+        import torch
+        from .._lib import check, get_lib
+        for key, n in self.pending_.items():
+            if n:
+                st = self.dev_[key]
+                with torch.cuda.device(st.device):
+                    check(get_lib().mm_rng_advance(st.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "rng_advance")
+                self.pending_[key] = 0
 
 
 _TRACKER = RngStatesTracker()

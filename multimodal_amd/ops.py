@@ -167,8 +167,10 @@ def bias_gelu_bwd(g, y, bias, mode, out=None):
     return out
 
 
-def bias_dropout_add(x, bias, residual, p, training, seed=0, offset=0, want_mask=False):
-    _need_cuda(x, bias, residual)
+def bias_dropout_add(x, bias, residual, p, training, seed=0, offset=0, want_mask=False, rng_state=None):
+    """rng_state: device int64[2] {seed, base offset} (mpu.get_cuda_rng_tracker().draw_device): the mask is then drawn from
+    (rng_state[0], rng_state[1] + offset) read at run time, and `seed` is ignored."""
+    _need_cuda(x, bias, residual, rng_state)
     x = x.contiguous()
     cols = x.size(-1)
     if bias is not None:
@@ -178,9 +180,16 @@ def bias_dropout_add(x, bias, residual, p, training, seed=0, offset=0, want_mask
     residual = residual.contiguous() if residual is not None else None
     out = torch.empty_like(x)
     keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if (want_mask and training and p > 0) else None
-    check(get_lib().mm_bias_dropout_add(out.data_ptr(), x.data_ptr(), _ptr(bias), _ptr(residual), _ptr(keep),
-                                        x.numel() // cols, cols, float(p), int(bool(training)), int(seed), int(offset),
-                                        dtype_code(x.dtype), _stream()), "bias_dropout_add")
+    if rng_state is not None:
+        if rng_state.dtype != torch.int64 or rng_state.numel() != 2:
+            raise RuntimeError("bias_dropout_add: rng_state must be a device int64[2] tensor {seed, base offset}")
+        check(get_lib().mm_bias_dropout_add_devrng(out.data_ptr(), x.data_ptr(), _ptr(bias), _ptr(residual), _ptr(keep),
+                                                   x.numel() // cols, cols, float(p), int(bool(training)), rng_state.data_ptr(),
+                                                   int(offset), dtype_code(x.dtype), _stream()), "bias_dropout_add_devrng")
+    else:
+        check(get_lib().mm_bias_dropout_add(out.data_ptr(), x.data_ptr(), _ptr(bias), _ptr(residual), _ptr(keep),
+                                            x.numel() // cols, cols, float(p), int(bool(training)), int(seed), int(offset),
+                                            dtype_code(x.dtype), _stream()), "bias_dropout_add")
     return (out, keep) if want_mask else out
 
 
@@ -277,6 +286,11 @@ def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, wa
     if aux is not None:
         return c, aux.view(*a.shape[:-1], N)
     return (c, None) if want_aux else c
+
+
+def gemm_nt_kernel_name(M, N, K, epilogue=_lib.EPI_NONE):
+    """Name of the kernel mm_gemm_nt dispatches for a contiguous 16-byte aligned problem of this shape (host-only query)."""
+    return get_lib().mm_gemm_nt_kernel_name(M, N, K, epilogue).decode()
 
 
 def qkv_rotary_supported(hn, d, n_out, k_in, rows, b):

@@ -63,6 +63,11 @@ class FusedAdam:
         self._grad_ptrs = torch.zeros(len(params), dtype=torch.int64, device=dev)
         self._partial = torch.empty(self._nchunks, dtype=torch.float32, device=dev)
         self._step = torch.zeros(1, dtype=torch.int32, device=dev)
+        # the learning rate lives in device memory (the update kernel reads it at run time), so that a step captured in a HIP
+        # graph follows a scheduler: step() uploads param_groups[0]["lr"] when it changed; before a graph REPLAY call sync_lr()
+        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self._lr_host = torch.full((1,), float(lr), dtype=torch.float32).pin_memory()
+        self._lr_uploaded = float(lr)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)  # pre-clip global norm of the last step
 
     @property
@@ -76,7 +81,31 @@ class FusedAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
+    def sync_lr(self):
+        """Upload param_groups[0]["lr"] to the device scalar the update kernel reads (no-op when unchanged).  step() calls it;
+        call it yourself before replaying a captured step after a scheduler changed the learning rate."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_uploaded:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdam: the learning rate changed inside a graph capture; call sync_lr() before capturing")
+            torch.cuda.current_stream().synchronize()  # the pinned scalar may still be in flight from the last upload
+            self._lr_host[0] = lr
+            self._lr_dev.copy_(self._lr_host, non_blocking=True)
+            self._lr_uploaded = lr
+
+    def refresh_master_from_params(self):
+        """master <- the parameters' CURRENT values.  The fp32 master copy is taken at construction; when weights are loaded
+        into the model afterwards (the reference builds the optimizer before load_checkpoint, megatron/training.py:646,690, and
+        relies on the DeepSpeed engine to refresh its fp32 copies) call this, or the first step() writes the stale master back
+        over the loaded weights.  `checkpointing.load_checkpoint(..., optimizer=opt)` does it."""
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.master[off:off + n].copy_(p.detach().reshape(-1).float())
+            off += (n + 7) // 8 * 8
+
     def step(self):
+        self.sync_lr()
         g = self.param_groups[0]
         params = g["params"]
         self._held = []  # keep this step's gradient tensors alive until the next step (the launches are asynchronous)
@@ -112,7 +141,7 @@ class FusedAdam:
         check(get_lib().mm_adam_step(self._param_ptrs.data_ptr(), self._grad_ptrs.data_ptr(), self.master.data_ptr(),
                                      self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self._chunks.data_ptr(), self._nchunks,
                                      self._partial.data_ptr(), self._step.data_ptr(), self.grad_norm.data_ptr(), float(g["lr"]),
-                                     float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), float(g["max_grad_norm"]),
+                                     self._lr_dev.data_ptr(), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), float(g["max_grad_norm"]),
                                      int(bool(g["bias_correction"])), self._dtype, torch.cuda.current_stream().cuda_stream),
               "adam_step")
 

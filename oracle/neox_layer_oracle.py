@@ -309,7 +309,9 @@ def layer_forward(cfg, shards, x, mask, training=True):
     all-reduce (mpu/mappings.py:29-48) is a sum over the list.  Reproduces the reference's behaviour
     that with gpt_j_residual both Row-linear biases are added on every rank BEFORE the single reduce
     (transformer.py:747-766), i.e. counted tp times.  Adapter weights are used when present
-    (keys attention.adapter.* / mlp.adapter.*)."""
+    (keys attention.adapter.* / mlp.adapter.*): with gpt_j_residual the wrapped Row linears return their PARTIAL sums
+    (parallel_output=True, transformer.py:690,703), so each rank's adapter - ReLU included - acts on that rank's partial sum
+    before the single reduce (adapter.py:109-117)."""
     tp = len(shards)
     assert tp == cfg.tp
     eps = cfg.layernorm_epsilon
@@ -341,14 +343,22 @@ def layer_forward(cfg, shards, x, mask, training=True):
             partial.append(bias_dropout_add(mo, mb.expand_as(mo), ao, pd, training))
         red = partial[0] if tp == 1 else torch.stack(partial).sum(0)
         return x + red
-    # sequential residual (transformer.py:767-799): each Row linear all-reduces, bias added once after
+    # sequential residual (transformer.py:767-799): each Row linear all-reduces INSIDE the wrapped module
+    # (parallel_output=False, layers.py:747-748), so an AdapterWrapper sees the reduced output and every rank computes the
+    # same adapter result from its own (identical) copy of the adapter weights - rank 0's copy stands for all of them here;
+    # the Row bias is added once, after
+    p0 = shards[0]
     ln1 = [layer_norm(x, p["input_layernorm.weight"], p["input_layernorm.bias"], eps) for p in shards]
-    outs = [attn_of(p, h_in) for p, h_in in zip(shards, ln1)]
+    outs = [self_attention(cfg, p, h_in, mask) for p, h_in in zip(shards, ln1)]
     ao = outs[0][0] if tp == 1 else torch.stack([o for o, _ in outs]).sum(0)
+    if "attention.adapter.0.weight" in p0:
+        ao = adapter(p0, "attention.", ao)
     a = bias_dropout_add(ao, outs[0][1].expand_as(x), x, pd, training)
     ln2 = [layer_norm(a, p["post_attention_layernorm.weight"], p["post_attention_layernorm.bias"], eps) for p in shards]
-    outs = [mlp_of(p, h_in) for p, h_in in zip(shards, ln2)]
+    outs = [mlp(cfg, p, h_in) for p, h_in in zip(shards, ln2)]
     mo = outs[0][0] if tp == 1 else torch.stack([o for o, _ in outs]).sum(0)
+    if "mlp.adapter.0.weight" in p0:
+        mo = adapter(p0, "mlp.", mo)
     return bias_dropout_add(mo, outs[0][1].expand_as(a), a, pd, training)
 
 
@@ -377,3 +387,24 @@ def cross_entropy_loss(logits, labels, loss_mask):
     losses = F.cross_entropy(logits.float().view(-1, logits.size(-1)), labels.reshape(-1), reduction="none")
     lm = loss_mask.reshape(-1)
     return torch.sum(losses * lm) / lm.sum()
+
+
+def vocab_parallel_cross_entropy(logit_shards, target):
+    """_VocabParallelCrossEntropy (megatron/mpu/cross_entropy.py:27-112) with the TP group simulated in-process:
+    `logit_shards` is a list (one per TP rank) of fp32 [..., V/p] partitions; the three all-reduces (MAX :33, SUM :68,
+    SUM :78) are reductions over the list.  Returns the per-token loss (target's shape); autograd through it gives the
+    reference's hand-written backward, (softmax - onehot) * grad_output (:93-112) - the shift by the (detached) maximum
+    has zero derivative."""
+    vp = logit_shards[0].size(-1)
+    mx = torch.stack([x.detach().max(dim=-1)[0] for x in logit_shards]).max(dim=0)[0]
+    predicted = 0.0
+    sum_exp = 0.0
+    for r, x in enumerate(logit_shards):
+        sh = x - mx.unsqueeze(-1)
+        lo, hi = r * vp, (r + 1) * vp                       # VocabUtility.vocab_range_from_per_partition_vocab_size
+        outside = (target < lo) | (target >= hi)
+        local = (target - lo).masked_fill(outside, 0)
+        pr = torch.gather(sh, -1, local.unsqueeze(-1)).squeeze(-1)
+        predicted = predicted + pr.masked_fill(outside, 0.0)
+        sum_exp = sum_exp + torch.exp(sh).sum(dim=-1)
+    return torch.log(sum_exp) - predicted

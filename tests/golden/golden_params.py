@@ -65,3 +65,22 @@ def stack_init(rng, V, h, L):
     init["fln.b"] = rng_t(rng, (h,), 0.1)
     init["head"] = rng_t(rng, (V, h), 0.05)
     return init
+
+
+ADAPTER_KEYS = [f"{loc}.adapter.{i}.{wb}" for loc in ("attention", "mlp") for i in (0, 2) for wb in ("weight", "bias")]
+
+
+def adapter_params(rng, h, r):
+    """Adapter weights (megatron/model/adapter.py:18-25 shapes) for both wrappers, in ADAPTER_KEYS order.  The first Linear's
+    bias is pushed to +-1 and its weight kept small (0.004, the order of the reference's own init std 1e-3, adapter.py:28-33)
+    so that the ReLU inputs, 1 +- ~0.15, stay away from the kink: a kink crossing differs between ANY two precisions, costs a
+    whole W1 row in dx, and says nothing about parity."""
+    out = {}
+    for loc in ("attention", "mlp"):
+        for i, shape in ((0, (r, h)), (2, (h, r))):
+            w = rng_t(rng, shape, 0.004 if i == 0 else 0.05)
+            b = rng_t(rng, (shape[0],), 0.05)
+            if i == 0:
+                b = torch.where(torch.arange(shape[0]) % 2 == 0, 1.0, -1.0) + b
+            out[f"{loc}.adapter.{i}.weight"], out[f"{loc}.adapter.{i}.bias"] = w, b
+    return out

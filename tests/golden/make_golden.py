@@ -67,6 +67,18 @@ def install_shims():
     torch.cuda.current_device = lambda: "cpu"  # transformer.py:342 hard-codes it
 
 
+def install_torchtyping_stub():
+    """megatron/model/adapter.py:3 imports torchtyping only for annotations; an environment shim that touches no arithmetic."""
+    tt = types.ModuleType("torchtyping")
+
+    class TensorType:
+        def __class_getitem__(cls, item):
+            return torch.Tensor
+
+    tt.TensorType = TensorType
+    sys.modules["torchtyping"] = tt
+
+
 def init_dist(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -154,6 +166,104 @@ def layer_case_name(c, tp, rank=None):
     if rank is not None:
         nm += "_r%d" % rank
     return nm
+
+
+# ------------------------------------------------------------------- head size 128 (summit-1-3B / 6-7B shapes)
+# configs/summit-1-3B.yml:20-26 (h=2304, n=18), configs/6-7B.yml:9-15 (h=4096, n=32): hn = 128, sequential residual,
+# exact-erf GeLU, rotary_pct 1.0
+HN128_SMALL = [dict(s=64, b=2, h=256, n=2, dt=_dt, rotary_pct=1.0, gpt_j=False, gelu_fusion=False) for _dt in ("f32", "bf16")]
+HN128_1_3B = dict(s=128, b=1, h=2304, n=18, dt="bf16", rotary_pct=1.0, gpt_j=False, gelu_fusion=False)   # TP = 2
+HN128_6_7B = dict(s=64, b=1, h=4096, n=32, dt="bf16", rotary_pct=1.0, gpt_j=False, gelu_fusion=False)    # TP = 8
+TP8_STORE_RANKS = (0, 5)
+
+
+# ------------------------------------------------------------------- layer wrapped with the reference's adapters
+ADAPTER_CASES = []
+for _dt in ("f32", "bf16"):
+    ADAPTER_CASES.append(dict(s=64, b=2, h=512, n=8, dt=_dt, rotary_pct=0.25, gpt_j=True, gelu_fusion=True))
+    ADAPTER_CASES.append(dict(s=64, b=2, h=512, n=8, dt=_dt, rotary_pct=1.0, gpt_j=False, gelu_fusion=False))
+
+
+def run_adapter_case(name, s, b, h, n, dt, rotary_pct, gpt_j, gelu_fusion, tp, rank, seed):
+    """ParallelTransformerLayer wrapped by the reference's own add_adapters (megatron/model/adapter.py:119-151, as called at
+    megatron/training.py:421-432) with the LM frozen (training.py:454-459): only adapter parameters get gradients."""
+    from megatron.model.transformer import ParallelTransformerLayer
+    from megatron.model.adapter import add_adapters
+    from megatron.model.gpt2_model_mask import gpt2_attention_mask_func
+    from golden_params import adapter_params, ADAPTER_KEYS
+
+    rng = np.random.default_rng(seed)
+    args = make_args(h, n, 2, s, dt, rotary_pct, gpt_j, gelu_fusion, tp)
+    layer = ParallelTransformerLayer(
+        neox_args=args, attention_mask_func=gpt2_attention_mask_func,
+        init_method=torch.nn.init.zeros_, output_layer_init_method=torch.nn.init.zeros_,
+        layer_number=0, rotary=True)
+    master = master_params(rng, h)
+    x = rng_t(rng, (s, b, h))
+    dy = rng_t(rng, (s, b, h))
+    ad = adapter_params(rng, h, h // 8)
+    with torch.no_grad():
+        sd = dict(layer.named_parameters())
+        for k in PARAM_ORDER:
+            sd[k].copy_(shard(k, master[k], rank, tp))
+    holder = torch.nn.ModuleList([layer])
+    add_adapters(args, holder, downsample_factor=8, location="mlp")
+    add_adapters(args, holder, downsample_factor=8, location="attention")
+    sd = dict(layer.named_parameters())
+    assert "attention.attn_block.dense.weight" in sd and "mlp.adapter.2.bias" in sd, sorted(sd)
+    with torch.no_grad():
+        for k in ADAPTER_KEYS:  # plain nn.Linear: identical on every TP rank
+            sd[k].copy_(ad[k])
+    for nme, p in layer.named_parameters():
+        p.requires_grad = "adapter" in nme
+    layer = layer.to(DT[dt])
+    layer.train()
+    xin = x.to(DT[dt]).requires_grad_(True)
+    y = layer(xin, causal_mask(s))
+    y.backward(dy.to(DT[dt]))
+    out = {"x": xin.detach(), "dy": dy.to(DT[dt]), "y": y.detach(), "dx": xin.grad}
+    sd = dict(layer.named_parameters())
+    for k in ADAPTER_KEYS:
+        out["g." + k] = sd[k].grad
+    assert all(p.grad is None for nme, p in layer.named_parameters() if "adapter" not in nme)
+    psum = float(sum(p.detach().double().abs().sum() for p in layer.parameters()))
+    meta = dict(param_abs_sum=psum, s=s, b=b, h=h, n=n, dtype=dt, rotary_pct=rotary_pct, gpt_j_residual=gpt_j,
+                bias_gelu_fusion=gelu_fusion, tp=tp, rank=rank, seed=seed, adapter_downsample_factor=8,
+                state_dict_keys=sorted(layer.state_dict().keys()),
+                source="megatron/model/transformer.py:644-801 wrapped by megatron/model/adapter.py:95-151 run on CPU")
+    _io.save(name, out, meta)
+    print("wrote", name, "y[0,0,:3]=", y.detach().float()[0, 0, :3].tolist())
+
+
+def adapter_case_name(c, tp, rank=None):
+    return "adapter_" + layer_case_name(c, tp, rank)
+
+
+# ------------------------------------------------------------------- vocab-parallel cross entropy
+CE_CASES = [dict(b=2, s=48, V=2048, seed=7100), dict(b=1, s=4, V=50304, seed=7101)]
+
+
+def run_ce_case(c, tp, rank):
+    """mpu.vocab_parallel_cross_entropy(output.float().contiguous(), labels) as megatron/model/gpt2_model.py:52-70 calls it
+    (megatron/mpu/cross_entropy.py:27-117), this rank's vocabulary partition of seeded bf16 logits."""
+    from megatron import mpu
+    rng = np.random.default_rng(c["seed"])
+    b, s, V = c["b"], c["s"], c["V"]
+    logits = rng_t(rng, (b, s, V), 3.0).to(torch.bfloat16)
+    labels = torch.from_numpy(rng.integers(0, V, (b, s)))
+    labels[0, 0], labels[0, 1] = 0, V - 1                       # partition edges
+    labels[0, 2], labels[0, 3] = V // 2 - 1, V // 2
+    gout = torch.from_numpy(rng.random((b, s)).astype(np.float32))  # upstream gradient (loss_mask / sum in the caller)
+    vp = V // tp
+    mine16 = logits[..., rank * vp:(rank + 1) * vp].contiguous().requires_grad_(True)
+    mine32 = mine16.float().contiguous()
+    mine32.retain_grad()
+    loss = mpu.vocab_parallel_cross_entropy(mine32, labels)
+    loss.backward(gout)
+    name = "op_vocab_ce_V%d_tp%d" % (V, tp) + ("_r%d" % rank if tp > 1 else "")
+    _io.save(name, dict(logits=logits, labels=labels, gout=gout, loss=loss.detach(), dlogits=mine32.grad, dlogits16=mine16.grad),
+             dict(b=b, s=s, V=V, tp=tp, rank=rank, seed=c["seed"], source="megatron/mpu/cross_entropy.py:27-117 run on CPU (gloo)"))
+    print("wrote", name, "loss[0,:3]=", loss.detach()[0, :3].tolist())
 
 
 # ------------------------------------------------------------------- per-op cases
@@ -343,23 +453,44 @@ def install_mask_module():
     sys.modules["megatron.model.gpt2_model_mask"] = m
 
 
-def worker_tp(rank, world, port):
-    install_shims(); install_mask_module()
+def worker_tp(rank, world, port, which):
+    install_shims(); install_mask_module(); install_torchtyping_stub()
     init_dist(rank, world, port)
     from megatron import mpu
     mpu.initialize_model_parallel(world)
     torch.manual_seed(0)
-    for i, c in enumerate(TP_CASES):
-        run_layer_case(layer_case_name(c, world, rank), tp=world, rank=rank, seed=2000 + i, store_params=False, **c)
+    if "tp2" in which:
+        for i, c in enumerate(TP_CASES):
+            run_layer_case(layer_case_name(c, world, rank), tp=world, rank=rank, seed=2000 + i, store_params=False, **c)
+    if "hn128" in which and world == 2:
+        for i, c in enumerate(HN128_SMALL):
+            run_layer_case(layer_case_name(c, world, rank), tp=world, rank=rank, seed=5100 + i, store_params=False, **c)
+        run_layer_case(layer_case_name(HN128_1_3B, world, rank), tp=world, rank=rank, seed=5200, store_grads=False, **HN128_1_3B)
+    if "hn128" in which and world == 8:
+        torch.set_num_threads(1)
+        c = HN128_6_7B
+        if rank in TP8_STORE_RANKS:
+            run_layer_case(layer_case_name(c, world, rank), tp=world, rank=rank, seed=5300, store_grads=False, **c)
+        else:  # takes part in the collectives; its own results are not stored
+            run_layer_case("_discard_r%d" % rank, tp=world, rank=rank, seed=5300, store_grads=False, **c)
+            os.remove(os.path.join(HERE, "_discard_r%d.npz" % rank))
+    if "adapters" in which and world == 2:
+        for i, c in enumerate(ADAPTER_CASES):
+            run_adapter_case(adapter_case_name(c, world, rank), tp=world, rank=rank, seed=6100 + i, **c)
+    if "ce" in which and world == 2:
+        for c in CE_CASES:
+            run_ce_case(c, world, rank)
     torch.distributed.barrier()
 
 
 def main():
-    which = sys.argv[1:] or ["ops", "layers", "big", "stack", "tp2"]
-    if "tp2" in which:
-        import torch.multiprocessing as mp
-        mp.spawn(worker_tp, args=(2, 29533), nprocs=2, join=True)
-    install_shims(); install_mask_module()
+    which = sys.argv[1:] or ["ops", "layers", "big", "stack", "tp2", "hn128", "adapters", "ce"]
+    import torch.multiprocessing as mp
+    if {"tp2", "hn128", "adapters", "ce"} & set(which):
+        mp.spawn(worker_tp, args=(2, 29533, which), nprocs=2, join=True)
+    if "hn128" in which:
+        mp.spawn(worker_tp, args=(8, 29534, which), nprocs=8, join=True)
+    install_shims(); install_mask_module(); install_torchtyping_stub()
     init_dist(0, 1, 29532)
     from megatron import mpu
     mpu.initialize_model_parallel(1)
@@ -376,6 +507,15 @@ def main():
         run_layer_case(layer_case_name(c, 1), tp=1, rank=0, seed=4100, store_grads=False, **c)
     if "stack" in which:
         gen_stack()
+    if "hn128" in which:
+        for i, c in enumerate(HN128_SMALL):
+            run_layer_case(layer_case_name(c, 1), tp=1, rank=0, seed=5000 + i, **c)
+    if "adapters" in which:
+        for i, c in enumerate(ADAPTER_CASES):
+            run_adapter_case(adapter_case_name(c, 1), tp=1, rank=0, seed=6000 + i, **c)
+    if "ce" in which:
+        for c in CE_CASES:
+            run_ce_case(c, 1, 0)
 
 
 if __name__ == "__main__":

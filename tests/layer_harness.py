@@ -33,13 +33,17 @@ def build_hip_layer(args, master, device, rank=0, tp=1):
     return layer.to(device)
 
 
-def oracle_layer_fp32(meta_or_cfg, master, x16, dy16, dtype, tp=1):
-    """fp32 oracle on the SAME 16-bit-rounded parameters and inputs (the yardstick for 16-bit error)."""
+def oracle_layer_fp32(meta_or_cfg, master, x16, dy16, dtype, tp=1, adapters=None):
+    """fp32 oracle on the SAME 16-bit-rounded parameters and inputs (the yardstick for 16-bit error).  `adapters`
+    (golden_params.adapter_params): every simulated rank gets its own copy, as every reference rank holds one."""
     cfg = meta_or_cfg
     shared = {k: master[k].to(dtype).float().requires_grad_(True) for k in golden_params.PARAM_ORDER
               if golden_params.shard(k, master[k], 0, 2) is master[k]}
     shards = [{k: shared[k] if k in shared else golden_params.shard(k, master[k], r, tp).to(dtype).float().requires_grad_(True)
                for k in golden_params.PARAM_ORDER} for r in range(tp)]
+    if adapters is not None:
+        for sh in shards:
+            sh.update({k: v.to(dtype).float().requires_grad_(True) for k, v in adapters.items()})
     xin = x16.float().clone().requires_grad_(True)
     y = O.layer_forward(cfg, shards, xin, O.causal_mask(x16.size(0)))
     y.backward(dy16.float())

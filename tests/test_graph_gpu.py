@@ -1,58 +1,119 @@
 """The C-ABI entry points neither allocate nor synchronise, so a whole training step (forward, backward, gradient
 clipping, fused Adam) can be captured in a HIP graph and replayed: the replayed step must reproduce the eager step bit
-for bit (same kernels, same order, same data)."""
+for bit (same kernels, same order, same data) - INCLUDING a fresh dropout mask per replay and a learning rate that
+follows the scheduler (both live in device memory; mpu/random.py, optim.py)."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 
-def test_hip_graph_replay_equals_eager_step(cuda_device):
+def _run(cuda_device, cfg_name, use_graph, steps, lr_schedule):
+    """bench.py's closure: FusedAdam(max_grad_norm) over the trainable parameters, zero_grad(set_to_none=True) inside the
+    step, the layer's two HIP streams on, end_of_step() after the backward.  Returns (losses, final parameters)."""
     from multimodal_amd import harness, mpu
+    from multimodal_amd.optim import FusedAdam
     mpu.destroy_model_parallel()
     mpu.initialize_model_parallel(1)
-    mpu.model_parallel_cuda_manual_seed(7)
-    cfg = harness.CONFIGS["tiny"]
+    mpu.model_parallel_cuda_manual_seed(7)  # also resets the dropout counters (host and device)
+    cfg = harness.CONFIGS[cfg_name]
+    torch.manual_seed(5)
+    model = harness.MagmaStack(cfg, dtype=torch.bfloat16, device=cuda_device)
+    model.train()
+    params = model.trainable_parameters()
+    opt = FusedAdam(params, lr=lr_schedule[0], betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+    batches = [harness.synthetic_batch(cfg, cuda_device, seed=3 + i) for i in range(3)]
+    static = [t.clone() if t is not None else None for t in batches[0]]
 
-    def build():
-        torch.manual_seed(5)
-        model = harness.MagmaStack(cfg, dtype=torch.bfloat16, device=cuda_device)
-        model.train()
-        params = model.trainable_parameters()
-        opt = torch.optim.Adam(params, lr=1e-2, fused=True, capturable=True)
-        return model, params, opt
+    def load(i):
+        for dst, src in zip(static, batches[i % len(batches)]):
+            if dst is not None:
+                dst.copy_(src)
 
-    batch = harness.synthetic_batch(cfg, cuda_device, seed=3)
-
-    def step(model, params, opt):
-        opt.zero_grad(set_to_none=False)
-        loss = model(*batch)
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model(*static)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        harness.end_of_step()
         opt.step()
         return loss
 
-    # eager: warm-up steps + 2 more
-    m1, p1, o1 = build()
-    for _ in range(3):
-        step(m1, p1, o1)
-    eager_losses = [float(step(m1, p1, o1).detach()) for _ in range(2)]
+    warm = 3
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(warm):
+            load(i)
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    losses = []
+    if use_graph:
+        load(warm)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            gl = step()                # capture only records: nothing runs here
+        for i in range(steps):
+            load(warm + i)
+            opt.param_groups[0]["lr"] = lr_schedule[i]
+            opt.sync_lr()              # the scheduler's value reaches the captured update kernel through device memory
+            g.replay()
+            losses.append(float(gl.detach()))
+    else:
+        for i in range(steps):
+            load(warm + i)
+            opt.param_groups[0]["lr"] = lr_schedule[i]
+            losses.append(float(step().detach()))
+    torch.cuda.synchronize()
+    return losses, [p.detach().clone() for p in params], model
 
-    # graph: identical warm-up on a side stream (capture needs warmed-up allocator / optimizer state), then capture one step and replay it
-    m2, p2, o2 = build()
+
+@pytest.mark.parametrize("cfg_name", ["tiny_magma", "tiny"])
+def test_hip_graph_replay_equals_eager_step(cuda_device, cfg_name):
+    sched = [1e-2, 5e-3, 2e-3]
+    l_eager, p_eager, _ = _run(cuda_device, cfg_name, False, 3, sched)
+    l_graph, p_graph, _ = _run(cuda_device, cfg_name, True, 3, sched)
+    assert l_graph == l_eager
+    for a, b in zip(p_eager, p_graph):
+        assert torch.equal(a, b)
+    # the schedule matters (a replay that kept the captured lr would have matched a constant-lr run instead)
+    l_const, p_const, _ = _run(cuda_device, cfg_name, False, 3, [1e-2] * 3)
+    assert any(not torch.equal(a, b) for a, b in zip(p_eager, p_const))
+
+
+def test_replayed_dropout_draws_fresh_masks(cuda_device):
+    """Two replays of one captured dropout launch on the same input give different masks; the masks are the ones the eager
+    sequence of calls draws."""
+    from multimodal_amd import functional as Fn, mpu
+    mpu.destroy_model_parallel()
+    mpu.initialize_model_parallel(1)
+    x = torch.randn(64, 256, device=cuda_device).bfloat16()
+
+    def draw_and_commit():
+        tr = mpu.get_cuda_rng_tracker()
+        st, pos = tr.draw_device(x.device)
+        y = Fn.bias_dropout_add(x, None, None, 0.5, True, 0, pos, rng_state=st)
+        tr.commit()
+        return y
+
+    mpu.model_parallel_cuda_manual_seed(11)
+    eager = [draw_and_commit().clone() for _ in range(3)]
+    mpu.model_parallel_cuda_manual_seed(11)
+    first = draw_and_commit().clone()       # creates the device state outside the capture
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        for _ in range(3):
-            step(m2, p2, o2)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = draw_and_commit()
     torch.cuda.current_stream().wait_stream(s)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        loss = step(m2, p2, o2)        # capture only records: nothing runs here
-    graph_losses = []
+    outs = [first]
     for _ in range(2):
         g.replay()
-        graph_losses.append(float(loss.detach()))
-    assert graph_losses == eager_losses
-    for a, b in zip(p1, p2):
+        outs.append(y.clone())
+    torch.cuda.synchronize()
+    for a, b in zip(eager, outs):
         assert torch.equal(a, b)
+    assert not torch.equal(outs[1], outs[2])
+    keep = (outs[1] != 0).float().mean().item()
+    assert 0.45 < keep < 0.55

@@ -141,6 +141,42 @@ def test_layer_with_adapters_vs_oracle(cuda_device):
     assert grads["attention.attn_block.dense.weight"] is None and grads["input_layernorm.weight"] is None
 
 
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(golden_io.HERE, "adapter_layer_*_bf16_*_tp1.npz"))))
+def test_layer_with_adapters_matches_reference_fixture(cuda_device, name):
+    """The HIP layer wrapped by add_adapters against the REFERENCE layer wrapped by its own add_adapters
+    (tests/golden/make_golden.py::run_adapter_case; megatron/model/adapter.py:95-151), both residual variants, LM frozen."""
+    from multimodal_amd.model import add_adapters
+    t, meta = golden_io.load(name)
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(meta["seed"])
+    master = golden_params.master_params(rng, meta["h"])
+    golden_params.rng_t(rng, (meta["s"], meta["b"], meta["h"]))  # x, dy: the generator's draw order
+    golden_params.rng_t(rng, (meta["s"], meta["b"], meta["h"]))
+    ad = golden_params.adapter_params(rng, meta["h"], meta["h"] // meta["adapter_downsample_factor"])
+    args = LH.make_neox_args(meta["h"], meta["n"], dtype, meta["rotary_pct"], meta["gpt_j_residual"], meta["bias_gelu_fusion"],
+                             softmax_fusion=meta["gpt_j_residual"])
+    layer = LH.build_hip_layer(args, master, cuda_device)
+    holder = torch.nn.ModuleList([layer])
+    add_adapters(args, holder, downsample_factor=meta["adapter_downsample_factor"], location="mlp")
+    add_adapters(args, holder, downsample_factor=meta["adapter_downsample_factor"], location="attention")
+    sd = dict(layer.named_parameters())
+    with torch.no_grad():
+        for k in golden_params.ADAPTER_KEYS:
+            sd[k].copy_(ad[k].to(dtype))
+    for nme, p in layer.named_parameters():
+        p.requires_grad = "adapter" in nme
+    assert set(layer.state_dict().keys()) == set(meta["state_dict_keys"])
+    y, dx, grads = LH.run_hip_layer(layer, t["x"], t["dy"], cuda_device)
+    cfg = O.LayerConfig(meta["h"], meta["n"], rotary_pct=meta["rotary_pct"], gpt_j_residual=meta["gpt_j_residual"],
+                        bias_gelu_fusion=meta["bias_gelu_fusion"])
+    y32, dx32, shards = LH.oracle_layer_fp32(cfg, master, t["x"], t["dy"], dtype, adapters=ad)
+    _check("y", y, t["y"], y32)
+    _check("dx", dx, t["dx"], dx32)
+    for k in golden_params.ADAPTER_KEYS:
+        _check("grad " + k, grads[k], t["g." + k], shards[0][k].grad, factor=3.0)
+    assert all(g is None for k, g in grads.items() if "adapter" not in k)
+
+
 @pytest.mark.parametrize("dt", ["bf16"])
 def test_stack_loss_curve_on_gpu(cuda_device, dt):
     """20 Adam steps of the 2-layer stack through the HIP layers reproduce the reference's loss curve (stated tolerance:

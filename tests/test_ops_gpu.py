@@ -404,6 +404,29 @@ def test_cross_entropy_fwd_bwd(ops, cuda_device, T, V):
     ulp_close(d, x.grad.bfloat16(), torch.bfloat16, ulps=1, atol=1e-7)
 
 
+@pytest.mark.parametrize("V", [2048, 50304])
+def test_cross_entropy_vs_reference_fixture(ops, cuda_device, V):
+    """mpu.vocab_parallel_cross_entropy at TP = 1, and the one-pass loss + gradient kernel, against what the reference's
+    _VocabParallelCrossEntropy computed for the same bf16 logits (tests/golden/op_vocab_ce_V*_tp1.npz;
+    megatron/mpu/cross_entropy.py:27-117 called as gpt2_model.py:52-70 does, on output.float())."""
+    from multimodal_amd import mpu
+    t, meta = golden_io.load(f"op_vocab_ce_V{V}_tp1")
+    if not mpu.model_parallel_is_initialized():
+        mpu.initialize_model_parallel(1)
+    lg = t["logits"].to(cuda_device).requires_grad_(True)
+    loss = mpu.vocab_parallel_cross_entropy(lg, t["labels"].to(cuda_device))
+    loss.backward(t["gout"].to(cuda_device))
+    torch.testing.assert_close(loss.cpu(), t["loss"], rtol=1e-5, atol=1e-5)
+    ref16 = t["dlogits"].bfloat16()   # the gradient the reference's bf16 logits receive (fp32 grad cast back by autograd)
+    assert torch.equal(t["dlogits16"], ref16)
+    ulp_close(lg.grad.cpu(), ref16, torch.bfloat16)
+    # one-pass kernel: same loss, gradient scaled by the row weight
+    buf = t["logits"].reshape(-1, V).to(cuda_device).clone()
+    loss1, _ = ops.cross_entropy_fwd_grad(buf, t["labels"].reshape(-1).to(cuda_device), t["gout"].reshape(-1).to(cuda_device))
+    torch.testing.assert_close(loss1.cpu(), t["loss"].reshape(-1), rtol=1e-5, atol=1e-5)
+    ulp_close(buf.cpu().view_as(ref16), ref16, torch.bfloat16)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("T,V", [(96, 50304), (33, 1024), (8, 65536), (5, 8), (16, 4104)])
 def test_cross_entropy_fwd_grad_one_pass(ops, cuda_device, dt, T, V):

@@ -80,3 +80,64 @@ def test_fused_adam_rejects_cpu_and_mixed(cuda_device):
     with pytest.raises(RuntimeError):
         FusedAdam([torch.nn.Parameter(torch.zeros(4, dtype=torch.bfloat16, device=cuda_device)),
                    torch.nn.Parameter(torch.zeros(4, dtype=torch.float16, device=cuda_device))])
+
+
+def test_step_after_load_checkpoint_uses_the_loaded_weights(cuda_device, tmp_path):
+    """The reference's order: optimizer built first, checkpoint loaded after (megatron/training.py:646,690).  The fp32 master
+    copy taken at construction must not overwrite the loaded weights on the first step; a saved FusedAdam state (step, master,
+    moments) comes back on resume."""
+    from multimodal_amd import checkpointing, harness, mpu
+    from multimodal_amd.optim import FusedAdam
+    mpu.destroy_model_parallel()
+    mpu.initialize_model_parallel(1)
+    mpu.model_parallel_cuda_manual_seed(3)
+    cfg = dict(harness.CONFIGS["tiny_magma"], image_embed_dropout_prob=0.0)
+    batch = harness.synthetic_batch(cfg, cuda_device, seed=1)
+
+    def build(seed):
+        torch.manual_seed(seed)
+        m = harness.MagmaStack(cfg, dtype=torch.bfloat16, device=cuda_device)
+        m.train()
+        return m, FusedAdam(m.trainable_parameters(), lr=1e-3, betas=(0.9, 0.95), max_grad_norm=1.0)
+
+    def one_step(m, opt):
+        opt.zero_grad()
+        m(*batch).backward()
+        opt.step()
+
+    # model A trains two steps and is saved WITH its optimizer state
+    ma, oa = build(1)
+    one_step(ma, oa)
+    one_step(ma, oa)
+    checkpointing.save_checkpoint(ma, str(tmp_path / "full"), 2, optimizer=oa)
+    checkpointing.save_checkpoint(ma, str(tmp_path / "weights_only"), 2)
+    one_step(ma, oa)  # the continuation every resume must reproduce
+    want = [p.detach().clone() for p in ma.trainable_parameters()]
+
+    # (1) resume with optimizer state: bit-identical continuation
+    mb, ob = build(2)  # different init: everything must come from the checkpoint
+    it, rep = checkpointing.load_checkpoint(mb, str(tmp_path / "full"), optimizer=ob)
+    assert it == 2 and rep["optimizer_state_loaded"]
+    one_step(mb, ob)
+    for a, b in zip(want, mb.trainable_parameters()):
+        assert torch.equal(a, b)
+
+    # (2) weights-only checkpoint: the master copy is refreshed from the loaded weights, so the first step moves the LOADED
+    # values (by at most ~lr per element), not the stale construction-time ones
+    mc, oc = build(2)
+    stale = [p.detach().clone() for p in mc.trainable_parameters()]
+    checkpointing.load_checkpoint(mc, str(tmp_path / "weights_only"), optimizer=oc)
+    loaded = [p.detach().clone() for p in mc.trainable_parameters()]
+    one_step(mc, oc)
+    for p, l0, s0 in zip(mc.trainable_parameters(), loaded, stale):
+        assert (p.float() - l0.float()).abs().max() <= 2e-3 + 2.0 ** -7 * l0.float().abs().max()
+        if (l0.float() - s0.float()).abs().max() > 1e-2:
+            assert (p.float() - s0.float()).abs().max() > 5e-3
+
+    # (3) without telling load_checkpoint about the optimizer the caller must refresh by hand: the documented failure mode
+    md, od = build(2)
+    checkpointing.load_checkpoint(md, str(tmp_path / "weights_only"))
+    od.refresh_master_from_params()
+    one_step(md, od)
+    for a, b in zip(mc.trainable_parameters(), md.trainable_parameters()):
+        assert torch.equal(a, b)

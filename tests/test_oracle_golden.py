@@ -173,22 +173,101 @@ def test_layer_tp1_matches_reference(name):
             assert (g - ref).abs().max() / scale <= (1e-4 if meta["dtype"] == "f32" else 3e-2), k
 
 
-@pytest.mark.parametrize("name", _layer_files(2))
-def test_layer_tp2_matches_reference(name):
+def _rank_fixtures(name_r0):
+    """{rank: tensors} of every rank stored for a TP fixture set (TP = 8 stores two of its eight ranks)."""
+    base = name_r0[:-1]
+    out = {}
+    for p in glob.glob(os.path.join(golden_io.HERE, base + "*.npz")):
+        r = int(os.path.basename(p)[len(base):-4])
+        out[r] = golden_io.load(base + str(r))[0]
+    return out
+
+
+@pytest.mark.parametrize("name", _layer_files(2) + _layer_files(8))
+def test_layer_tp_matches_reference(name):
+    """TP = 2 (both residual variants at head size 64, sequential at head size 128 incl. the summit-1-3B width h=2304, n=18)
+    and TP = 8 at the 6-7B width (h=4096, n=32): fixtures made by the reference with 2 / 8 gloo ranks."""
     t0, meta = golden_io.load(name)
-    t1, _ = golden_io.load(name[:-1] + "1")
-    y, dx, shards = _run_oracle_layer(meta, t0["x"], t0["dy"], 2)
-    tol = dict(rtol=1e-5, atol=1e-5) if meta["dtype"] == "f32" else dict(rtol=2 ** -6, atol=3e-2)
-    for t in (t0, t1):  # both ranks hold the same y / dx
+    tp = meta["tp"]
+    ranks = _rank_fixtures(name)
+    y, dx, shards = _run_oracle_layer(meta, t0["x"], t0["dy"], tp)
+    wide = meta["h"] >= 2048   # long bf16 contractions: eager CPU summation order (blocked differently for a stacked sum) shows
+    tol = dict(rtol=1e-5, atol=1e-5) if meta["dtype"] == "f32" else dict(rtol=2 ** -6, atol=6e-2 if wide else 3e-2)
+    for t in ranks.values():  # every rank holds the same y / dx
         torch.testing.assert_close(y.float(), t["y"].float(), **tol)
         torch.testing.assert_close(dx.float(), t["dx"].float(), **tol)
-    for r, t in enumerate((t0, t1)):
+    for r, t in ranks.items():
         for k in ("attention.query_key_value.bias", "mlp.dense_h_to_4h.bias", "attention.dense.bias", "input_layernorm.weight"):
             g = shards[r][k].grad.float()
             if k == "attention.dense.bias" and meta["gpt_j_residual"]:
-                g = g / 2  # gpt-j: every rank adds its own copy of the bias, so a rank's grad is 1/tp of the shared tensor's
+                g = g / tp  # gpt-j: every rank adds its own copy of the bias, so a rank's grad is 1/tp of the shared tensor's
             ref = t["g." + k].float()
             assert (g - ref).abs().max() / ref.abs().max().clamp_min(1e-6) <= (1e-4 if meta["dtype"] == "f32" else 3e-2), (r, k)
+
+
+def _adapter_files():
+    pat = os.path.join(golden_io.HERE, "adapter_layer_*.npz")
+    return sorted({os.path.basename(p)[:-4] for p in glob.glob(pat) if not os.path.basename(p)[:-4].endswith("_r1")})
+
+
+@pytest.mark.parametrize("name", _adapter_files())
+def test_layer_with_adapters_matches_reference(name):
+    """oracle.adapter / layer_forward with adapters against the reference layer wrapped by its own add_adapters
+    (megatron/model/adapter.py:95-151), LM frozen, TP = 1 and TP = 2.  Under TP = 2 with the GPT-J residual the adapter
+    (ReLU included) acts on each rank's PARTIAL sum; with the sequential residual it acts on the reduced output."""
+    t0, meta = golden_io.load(name)
+    tp, dt = meta["tp"], DT[meta["dtype"]]
+    ranks = {0: t0} if tp == 1 else _rank_fixtures(name)
+    rng = np.random.default_rng(meta["seed"])
+    master = golden_params.master_params(rng, meta["h"])
+    x = golden_params.rng_t(rng, (meta["s"], meta["b"], meta["h"])).to(dt)
+    dy = golden_params.rng_t(rng, (meta["s"], meta["b"], meta["h"])).to(dt)
+    ad = golden_params.adapter_params(rng, meta["h"], meta["h"] // meta["adapter_downsample_factor"])
+    assert torch.equal(x, t0["x"]) and torch.equal(dy, t0["dy"]), "seeded inputs do not regenerate"
+    shards = []
+    for r in range(tp):
+        p = {k: golden_params.shard(k, master[k], r, tp).to(dt) for k in golden_params.PARAM_ORDER}
+        p.update({k: v.to(dt).clone().requires_grad_(True) for k, v in ad.items()})  # one copy per rank, as in the reference
+        shards.append(p)
+    psum = float(sum(v.detach().double().abs().sum() for v in shards[0].values()))
+    assert abs(psum - meta["param_abs_sum"]) <= 1e-9 * meta["param_abs_sum"]
+    cfg = O.LayerConfig(meta["h"], meta["n"], rotary_pct=meta["rotary_pct"], gpt_j_residual=meta["gpt_j_residual"],
+                        bias_gelu_fusion=meta["bias_gelu_fusion"], tp=tp)
+    xin = x.clone().requires_grad_(True)
+    y = O.layer_forward(cfg, shards, xin, O.causal_mask(meta["s"]))
+    y.backward(dy)
+    f32 = meta["dtype"] == "f32"
+    tol = dict(rtol=1e-5, atol=2e-5) if f32 else dict(rtol=2 ** -6, atol=3e-2)
+    for r, t in ranks.items():
+        torch.testing.assert_close(y.detach().float(), t["y"].float(), **tol)
+        torch.testing.assert_close(xin.grad.float(), t["dx"].float(), **tol)
+        # sequential residual: every rank computes the same adapter on the reduced tensor; the simulation keeps rank 0's copy
+        src = shards[r] if meta["gpt_j_residual"] else shards[0]
+        for k in golden_params.ADAPTER_KEYS:
+            g, ref = src[k].grad.float(), t["g." + k].float()
+            assert (g - ref).abs().max() / ref.abs().max().clamp_min(1e-6) <= (1e-4 if f32 else 3e-2), (r, k)
+    # the wrapped layer's state-dict keys (adapter.py:106-107,25) as the product must expose them
+    assert "attention.attn_block.query_key_value.weight" in meta["state_dict_keys"] and "mlp.adapter.2.bias" in meta["state_dict_keys"]
+
+
+@pytest.mark.parametrize("V", [2048, 50304])
+@pytest.mark.parametrize("tp", [1, 2])
+def test_vocab_parallel_cross_entropy_matches_reference(V, tp):
+    """oracle.vocab_parallel_cross_entropy / cross_entropy_loss against mpu.vocab_parallel_cross_entropy run by the
+    reference on 1 and 2 gloo ranks (megatron/mpu/cross_entropy.py:27-117)."""
+    fx = [golden_io.load(f"op_vocab_ce_V{V}_tp{tp}" + (f"_r{r}" if tp > 1 else ""))[0] for r in range(tp)]
+    logits, labels, gout = fx[0]["logits"], fx[0]["labels"], fx[0]["gout"]
+    vp = V // tp
+    parts = [logits[..., r * vp:(r + 1) * vp].float().contiguous().requires_grad_(True) for r in range(tp)]
+    loss = O.vocab_parallel_cross_entropy(parts, labels)
+    loss.backward(gout)
+    for r in range(tp):
+        torch.testing.assert_close(loss.detach(), fx[r]["loss"], rtol=1e-6, atol=2e-6)
+        torch.testing.assert_close(parts[r].grad, fx[r]["dlogits"], rtol=1e-5, atol=1e-7)
+    # the TP = 1 masked-mean loss helper (gpt2_model.py:52-70) agrees with the per-token losses
+    lm = (gout > 0.3).float()
+    ref = (torch.cat([f["loss"] for f in fx[:1]]).view(-1) * lm.view(-1)).sum() / lm.sum()
+    torch.testing.assert_close(O.cross_entropy_loss(logits, labels, lm), ref, rtol=1e-5, atol=1e-5)
 
 
 def test_gptj_tp2_counts_row_biases_twice():

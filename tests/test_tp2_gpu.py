@@ -24,7 +24,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, names, q):
+def _worker(rank, world, port, names, q, kind="layer"):
+    """One TP rank: builds its shard of the HIP layer for every fixture set in `names`, runs forward + backward and checks
+    against the reference's fixture of that rank (ranks without a stored fixture only take part in the collectives).
+    kind "adapter": the layer is wrapped by add_adapters and the LM frozen (tests/golden/make_golden.py::run_adapter_case)."""
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -39,20 +42,42 @@ def _worker(rank, world, port, names, q):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     from multimodal_amd import mpu
-    mpu.initialize_model_parallel(2, fp32_allreduce=True)  # fp32 transport: exact for a 2-term sum, and gloo-safe
+    mpu.initialize_model_parallel(world, fp32_allreduce=True)  # fp32 transport: gloo-safe (RCCL bf16 path: tests/test_mpu_cpu.py)
     fails = []
     try:
         for name in names:
-            t, meta = golden_io.load(f"{name}_r{rank}")
+            have = golden_io.exists(f"{name}_r{rank}")
+            t, meta = golden_io.load(f"{name}_r{rank}" if have else f"{name}_r0")
             dtype = torch.bfloat16
-            master = golden_params.master_params(np.random.default_rng(meta["seed"]), meta["h"])
+            rng = np.random.default_rng(meta["seed"])
+            master = golden_params.master_params(rng, meta["h"])
             args = LH.make_neox_args(meta["h"], meta["n"], dtype, meta["rotary_pct"], meta["gpt_j_residual"],
-                                     meta["bias_gelu_fusion"], tp=2)
-            layer = LH.build_hip_layer(args, master, dev, rank=rank, tp=2)
+                                     meta["bias_gelu_fusion"], tp=world)
+            layer = LH.build_hip_layer(args, master, dev, rank=rank, tp=world)
+            ad = None
+            if kind == "adapter":
+                from multimodal_amd.model import add_adapters
+                golden_params.rng_t(rng, (meta["s"], meta["b"], meta["h"]))  # x, dy: the generator's draw order
+                golden_params.rng_t(rng, (meta["s"], meta["b"], meta["h"]))
+                ad = golden_params.adapter_params(rng, meta["h"], meta["h"] // meta["adapter_downsample_factor"])
+                holder = torch.nn.ModuleList([layer])
+                add_adapters(args, holder, downsample_factor=meta["adapter_downsample_factor"], location="mlp")
+                add_adapters(args, holder, downsample_factor=meta["adapter_downsample_factor"], location="attention")
+                sd = dict(layer.named_parameters())
+                with torch.no_grad():
+                    for k in golden_params.ADAPTER_KEYS:
+                        sd[k].copy_(ad[k].to(dtype))
+                for nme, p in layer.named_parameters():
+                    p.requires_grad = "adapter" in nme
+                if set(layer.state_dict().keys()) - {"attention.attn_block.rotary_emb.inv_freq"} != \
+                        set(meta["state_dict_keys"]) - {"attention.attn_block.rotary_emb.inv_freq"}:
+                    fails.append(f"{name} r{rank}: state-dict keys differ from the reference's wrapped layer")
             y, dx, grads = LH.run_hip_layer(layer, t["x"], t["dy"], dev)
+            if not have:
+                continue
             cfg = O.LayerConfig(meta["h"], meta["n"], rotary_pct=meta["rotary_pct"], gpt_j_residual=meta["gpt_j_residual"],
-                                bias_gelu_fusion=meta["bias_gelu_fusion"], tp=2)
-            y32, dx32, shards = LH.oracle_layer_fp32(cfg, master, t["x"], t["dy"], dtype, tp=2)
+                                bias_gelu_fusion=meta["bias_gelu_fusion"], tp=world)
+            y32, dx32, shards = LH.oracle_layer_fp32(cfg, master, t["x"], t["dy"], dtype, tp=world, adapters=ad)
 
             def chk(what, got, ref16, ref32, factor=2.0):
                 got, ref16 = got.float(), ref16.float()
@@ -64,6 +89,14 @@ def _worker(rank, world, port, names, q):
 
             chk("y", y, t["y"], y32)
             chk("dx", dx, t["dx"], dx32)
+            if kind == "adapter":
+                src = shards[rank] if meta["gpt_j_residual"] else shards[0]
+                for k in golden_params.ADAPTER_KEYS:
+                    if grads[k] is None:
+                        fails.append(f"{name} r{rank}: no gradient for {k}")
+                    else:
+                        chk("grad " + k, grads[k], t["g." + k], src[k].grad, factor=3.0)
+                continue
             for k in ("attention.query_key_value.bias", "mlp.dense_h_to_4h.bias", "attention.dense.bias",
                       "mlp.dense_4h_to_h.bias", "input_layernorm.weight", "attention.dense.weight"):
                 if "g." + k not in t:
@@ -71,7 +104,7 @@ def _worker(rank, world, port, names, q):
                 g32 = shards[rank][k].grad
                 if k.endswith("dense.bias") or k.endswith("4h_to_h.bias"):
                     if meta["gpt_j_residual"]:
-                        g32 = g32 / 2  # shared tensor in the simulation, one copy per rank in reality
+                        g32 = g32 / world  # shared tensor in the simulation, one copy per rank in reality
                 chk("grad " + k, grads[k], t["g." + k], g32, factor=3.0)
     except Exception as e:  # noqa: BLE001
         import traceback
@@ -81,20 +114,47 @@ def _worker(rank, world, port, names, q):
     torch.distributed.destroy_process_group()
 
 
-def test_tp2_layer_matches_reference_tp2_fixtures(cuda_device):
-    import golden_io
-    names = sorted({os.path.basename(p)[:-7] for p in glob.glob(os.path.join(golden_io.HERE, "layer_*_bf16_*_tp2_r0.npz"))})
-    assert len(names) >= 2
+def _run_ranks(world, names, kind="layer", timeout=150):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, _free_port_shared(), names, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, names, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=100) for _ in range(2)]
+    results = [q.get(timeout=timeout) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     fails = [f for _, fl in results for f in fl]
     assert not fails, "\n".join(fails)
+
+
+def _names(pattern):
+    import golden_io
+    return sorted({os.path.basename(p)[:-7] for p in glob.glob(os.path.join(golden_io.HERE, pattern))})
+
+
+def test_tp2_layer_matches_reference_tp2_fixtures(cuda_device):
+    """Both residual variants at head size 64, and the sequential variant at head size 128 (h=256, and the summit-1-3B width
+    h=2304 / n=18 -> 9 heads per rank, configs/summit-1-3B.yml:20-26)."""
+    names = _names("layer_*_bf16_*_tp2_r0.npz")
+    assert len(names) >= 4 and any("h2304" in n for n in names)
+    _run_ranks(2, names)
+
+
+def test_tp2_adapter_layer_matches_reference(cuda_device):
+    """The reference layer wrapped by its own add_adapters on two ranks: with the GPT-J residual each rank's adapter (ReLU
+    included) acts on that rank's PARTIAL sum before the single reduce; with the sequential residual on the reduced output."""
+    names = _names("adapter_layer_*_bf16_*_tp2_r0.npz")
+    assert len(names) == 2
+    _run_ranks(2, names, kind="adapter")
+
+
+def test_tp8_layer_matches_reference_6_7b_width(cuda_device):
+    """BASELINE configs[4]: the 6-7B shape (h=4096, n=32, hn=128, configs/6-7B.yml:9-15) at TP = 8 - eight processes on the one
+    GPU of the test box, fixtures from the reference on eight gloo ranks (ranks 0 and 5 stored)."""
+    names = _names("layer_*_bf16_*_tp8_r0.npz")
+    assert len(names) == 1
+    _run_ranks(8, names, timeout=300)
 
 
 _PORT = None
@@ -120,6 +180,21 @@ def _ce_worker(rank, world, port, q):
     mpu.initialize_model_parallel(2, fp32_allreduce=True)
     fails = []
     try:
+        # (a) the reference's own two-rank run (tests/golden/op_vocab_ce_V*_tp2_r{0,1}.npz, megatron/mpu/cross_entropy.py:27-117)
+        import golden_io
+        for V in (2048, 50304):
+            t, meta = golden_io.load(f"op_vocab_ce_V{V}_tp2_r{rank}")
+            vp = V // world
+            mine = t["logits"][..., rank * vp:(rank + 1) * vp].contiguous().to(dev).requires_grad_(True)
+            loss = mpu.vocab_parallel_cross_entropy(mine, t["labels"].to(dev))
+            loss.backward(t["gout"].to(dev))
+            if not torch.allclose(loss.cpu(), t["loss"], rtol=1e-5, atol=1e-5):
+                fails.append(f"rank {rank} V={V}: loss vs reference fixture max err {(loss.cpu() - t['loss']).abs().max().item():.3g}")
+            if not torch.equal(mine.grad.cpu(), t["dlogits"].bfloat16()) and \
+                    (mine.grad.float().cpu() - t["dlogits"]).abs().max().item() > 2.0 ** -8 * t["dlogits"].abs().max().item() + 1e-7:
+                fails.append(f"rank {rank} V={V}: dlogits vs reference fixture max err "
+                             f"{(mine.grad.float().cpu() - t['dlogits']).abs().max().item():.3g}")
+        # (b) against the full-vocabulary formula on fresh random logits
         T, V = 96, 2048
         g = torch.Generator().manual_seed(11)
         logits = (torch.randn(T, V, generator=g) * 3).bfloat16()
