@@ -66,6 +66,7 @@ PROTOTYPES = {
     "mm_embed_prefix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "mm_adam_chunk_elems": (c_int, []),
     "mm_adam_step": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p] + [c_float] * 5 + [c_int, c_int, c_void_p]),
+    "mm_debug_gemm256": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "mm_debug_probe_tr_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -204,7 +204,11 @@ extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, cons
         });
     }
     hipStream_t st = (hipStream_t)stream;
-    {   // large shapes: the pipelined 256-row kernel (gemm256.hip); it declines (returns 1) what it does not take
+    {   // large shapes: the ping-pong 256-row kernel (gemm_pp.hip); it declines (returns 1) what it does not take
+        const int rc = gemm_pp_try(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, dtype, st);
+        if (rc <= 0) return rc;
+    }
+    {   // the earlier pipelined 256x256 kernel (gemm256.hip), kept for same-process A/B (MM_GEMMPP=-1)
         const int rc = gemm256_try(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, dtype, st);
         if (rc <= 0) return rc;
     }
@@ -227,6 +231,8 @@ extern "C" const char* mm_gemm_nt_kernel_name(int M, int N, int K, int epilogue)
     (void)epilogue;
     if (M <= 0 || N <= 0 || K <= 0) return "none";
     if (K % 64 || N % 4) return "gemm_nt_generic_k";
+    const int bn = gemm_pp_tile(M, N, K, K, K);
+    if (bn) return bn == 256 ? "gemm_nt_pp_k<256>" : "gemm_nt_pp_k<128>";
     return gemm256_takes(M, N, K, K, K) ? "gemm_nt_256_k" : "gemm_nt_128_k";
 }
 
@@ -246,7 +252,9 @@ extern "C" int mm_gemm_nt_qkv_rotary(void* C, const void* A, const void* B, cons
     }
     const EpiExtra ex{b > 1 ? (uint32_t)((1ull << 32) / (uint64_t)b) + 1u : 0u, b, d, offset};
     hipStream_t st = (hipStream_t)stream;
-    const int rc = gemm256_try(C, const_cast<void*>(cos), A, B, bias, sin, M, N, K, lda, ldb, ldc, MM_EPI_BIAS_ROTARY, dtype, st, ex);
+    int rc = gemm_pp_try(C, const_cast<void*>(cos), A, B, bias, sin, M, N, K, lda, ldb, ldc, MM_EPI_BIAS_ROTARY, dtype, st, ex);
+    if (rc <= 0) return rc;
+    rc = gemm256_try(C, const_cast<void*>(cos), A, B, bias, sin, M, N, K, lda, ldb, ldc, MM_EPI_BIAS_ROTARY, dtype, st, ex);
     if (rc <= 0) return rc;
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);

@@ -77,7 +77,9 @@ __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T, int EPI, bool RES>
+// DBG (developer decomposition builds only, mm_debug_gemm256): bit 0 = no global->LDS loads inside the K loop, bit 1 = no LDS
+// fragment reads inside the loop, bit 2 = no epilogue stores, bit 3 = no MFMAs.  DBG = 0 everywhere in the product.
+template <typename T, int EPI, bool RES, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256_k(u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ A,
                                                         const u16* __restrict__ B, const u16* __restrict__ bias,
                                                         const u16* __restrict__ Rsd, int M, int N, int K, int lda, int ldb,
@@ -150,25 +152,37 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256_k(u16* __restrict__ C, u16
         }
         wg_barrier();
         read_item(fa0, fb0, a_addr(0, 0), b_addr(0, 0));
+        if (DBG & 2) read_item(fa1, fb1, a_addr(0, 1), b_addr(0, 1));
         for (int t = 0; t < nt; ++t) {
             const int st = t & 1;
-            read_item(fa1, fb1, a_addr(st, 1), b_addr(st, 1));
+            if (!(DBG & 2)) read_item(fa1, fb1, a_addr(st, 1), b_addr(st, 1));
+            if (DBG & 2) MM_WAIT(63, 0); else
             MM_WAIT(63, 12);  // F0 complete (LDS returns in order; only the 12 reads just issued may be outstanding)
             __builtin_amdgcn_sched_barrier(0);
-            mfma_item<T>(acc, fa0, fb0);
+            if (!(DBG & 8)) mfma_item<T>(acc, fa0, fb0);
             // my share of tile t+1 has landed; all my reads of tile t (F1 included) are done
             MM_WAIT(0, 0);
             wg_barrier();  // => tile t+1 visible to everyone, stage st free for everyone
-            if (t + 2 < nt) issue(t + 2, st);
-            read_item(fa0, fb0, a_addr(st ^ 1, 0), b_addr(st ^ 1, 0));  // item (t+1, 0); harmless stale read after the last tile
+            if (!(DBG & 1)) if (t + 2 < nt) issue(t + 2, st);
+            if (!(DBG & 2)) read_item(fa0, fb0, a_addr(st ^ 1, 0), b_addr(st ^ 1, 0));  // item (t+1, 0); harmless stale read after the last tile
             __builtin_amdgcn_sched_barrier(0);
-            mfma_item<T>(acc, fa1, fb1);
+            if (!(DBG & 8)) mfma_item<T>(acc, fa1, fb1);
         }
         MM_WAIT(0, 0);
         wg_barrier();  // every wave is done with the stages: LDS is reused by the epilogue
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    if (DBG & 4) {  // keep the accumulators (and, without MFMAs, the fragments) alive without storing anything real
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += acc[i][j][0] + acc[i][j][3];
+        sum += __uint_as_float(fa0[0][0] ^ fb0[0][0] ^ fa1[7][3] ^ fb1[3][3]);
+        if (sum == 12345.678f) C[0] = (u16)lane;
+        return;
+    }
     // ---- epilogue (coalesced through a wave-private 16 KiB LDS region)
     epilogue_staged<T, EPI, RES, 8>(acc, smem + wave * 16384, bm + wr * 128, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd, lane, ex);
 }
@@ -208,6 +222,34 @@ static int launch256_epi(void* C, void* aux, const void* A, const void* B, const
         case MM_EPI_GELU_TANH_BWD: return launch256<T, MM_EPI_GELU_TANH_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
         default: return launch256<T, MM_EPI_GELU_ERF_BWD>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
     }
+}
+
+template <int EPI, int DBG>
+static void launch256_dbg(void* C, void* aux, const void* A, const void* B, const void* bias, int M, int N, int K, hipStream_t st) {
+    const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
+    const int nwg = tiles_m * tiles_n;
+    int group_m = (nwg / 8) / tiles_n;
+    group_m = group_m < 1 ? 1 : (group_m > 8 ? 8 : group_m);
+    gemm_nt_256_k<BF16, EPI, false, DBG><<<dim3(nwg), dim3(512), 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
+                                                                         nullptr, M, N, K, K, K, N, tiles_m, tiles_n, group_m, EpiExtra{});
+}
+
+// Developer decomposition of the 256x256 kernel (bf16, contiguous operands, M, N multiples of 256, K of 64): see DBG above.
+int gemm256_debug(void* C, void* aux, const void* A, const void* B, const void* bias, int M, int N, int K, int gelu, int dbg,
+                  hipStream_t st) {
+    if (M % 256 || N % 256 || K % 64 || K < 128) return MM_EINVAL;
+#define MM_DBG_CASE(D)                                                                         \
+    case D:                                                                                     \
+        if (gelu) launch256_dbg<MM_EPI_BIAS_GELU_TANH, D>(C, aux, A, B, bias, M, N, K, st);    \
+        else launch256_dbg<MM_EPI_NONE, D>(C, aux, A, B, bias, M, N, K, st);                   \
+        break;
+    switch (dbg) {
+        MM_DBG_CASE(0) MM_DBG_CASE(1) MM_DBG_CASE(2) MM_DBG_CASE(3) MM_DBG_CASE(4) MM_DBG_CASE(5) MM_DBG_CASE(6) MM_DBG_CASE(7)
+        MM_DBG_CASE(8) MM_DBG_CASE(12) MM_DBG_CASE(14) MM_DBG_CASE(13)
+        default: return MM_EINVAL;
+    }
+#undef MM_DBG_CASE
+    return hipGetLastError() == hipSuccess ? MM_OK : MM_ELAUNCH;
 }
 
 // Shape policy: the 256x256 tile pays when its workgroups fill the 256 CUs in whole rounds (or in so many rounds that the

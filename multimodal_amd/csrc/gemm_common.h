@@ -217,6 +217,10 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
 }
 
 // gemm256.hip: returns MM_OK when it ran the problem, 1 when the shape is not one it takes (caller falls back), <0 on error.
+// gemm_pp.hip (the ping-pong 256 x {256,128} kernel): same return convention; gemm_pp_tile = the tile width it would use (0: declines)
+int gemm_pp_tile(int M, int N, int K, int lda, int ldb);
+int gemm_pp_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
+                int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st, const EpiExtra& ex = EpiExtra{});
 bool gemm256_takes(int M, int N, int K, int lda, int ldb);
 int gemm256_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
                 int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st, const EpiExtra& ex = EpiExtra{});

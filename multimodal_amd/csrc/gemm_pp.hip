@@ -1,0 +1,253 @@
+// gemm_pp.hip - "ping-pong" bf16/f16 MFMA GEMM  C[M,N] = A[M,K] * B[N,K]^T  with 256 x BN tiles (BN = 256 or 128), gfx950.
+//
+// Same contract and epilogues as gemm.hip / gemm256.hip (reference megatron/mpu/layers.py:557,745 F.linear).
+//
+// Why another kernel: tools/decompose_gemm256.py on the 256x256 kernel of gemm256.hip (M=8192 N=4096 K=1024, bias-GeLU):
+// MFMAs + barriers alone 41 us, loads + LDS reads + epilogue alone 53 us, the full kernel 82 us - close to the SUM.  In that
+// kernel all eight waves run the same program behind one barrier per K-tile, so the two waves of a SIMD reach their
+// global->LDS issue (8 LDS-DMA pieces, ~60-180 cycles of issue each), their 24 fragment reads and their 64 MFMAs at the same
+// time and take turns instead of overlapping.  Here the two waves of a SIMD run OPPOSITE phases:
+//
+//   waves 0-3 (group 0) | compute t   | load t+1   | compute t+1 | load t+2   | ...
+//   waves 4-7 (group 1) | load t      | compute t  | load t+1    | compute t+1| ...
+//                       ^ one s_barrier per phase (two per 64-deep K-tile)
+//
+//   compute phase: the wave's 2*MI*4 MFMAs (16x16x32) of one K-tile, back to back, every operand already in registers;
+//   load phase   : the wave's share of the global->LDS DMA of a later tile, then ALL fragment reads of its next tile
+//                  (2*(MI+4) ds_read_b128 into the registers the compute phase has just finished with).
+//   (A workgroup's waves go to the SIMDs in cyclic order, so every SIMD holds one wave of each group: in every phase each
+//    SIMD has exactly one wave issuing MFMAs and one wave issuing memory instructions.)
+//
+// Two 64-deep LDS stages (A 256 x 128 B, B BN x 128 B; lane-linear 8-row images, 16-byte chunk index XOR (row>>1)&7 on the
+// DMA source address and on the read address).  Tile T lives in stage T&1; its DMA is issued by group 0 in phase 2T-3 and by
+// group 1 in phase 2T-2, and first read in phase 2T-1: the stage was last read (tile T-2) in phases 2T-5 / 2T-4.  Every wave
+// drains its own DMA (vmcnt) before the barrier that precedes the first reader.  Hazard notes sit next to the code.
+//
+// BN = 256: waves 2(M) x 4(N), 128x64 per wave (the h->4h class and the LM head: >= 256 tiles).
+// BN = 128: waves 4(M) x 2(N),  64x64 per wave (the N = h class: M=8192, N=1024 is exactly 256 tiles = one per CU, where
+//           256x256 tiles would leave half the chip idle and 128x128 tiles move 2x the L2->LDS bytes per flop).
+#include "gemm_common.h"
+
+namespace mm {
+
+template <int BN_> struct PP {
+    static constexpr int BM = 256, BN = BN_;
+    static constexpr int ROWB = 128;  // bytes per tile row (64 k-elements)
+    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
+    static constexpr int NLA = BM / 64, NLB = BN / 64, NL = NLA + NLB;  // LDS-DMA instructions per wave per K-tile
+    static constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;
+    static constexpr int WM = BM / WAVES_M, MI = WM / 16;               // wave tile WM x 64: MI x 4 accumulators
+    static constexpr int NREADS = 2 * (MI + 4);                         // ds_read_b128 per wave per K-tile
+};
+
+constexpr int pp_waitcnt(int vm, int lgkm) { return (vm & 0xF) | (7 << 4) | ((lgkm & 0xF) << 8) | (((vm >> 4) & 3) << 14); }
+#define PP_WAIT(vm, lgkm) __builtin_amdgcn_s_waitcnt(pp_waitcnt(vm, lgkm))
+
+template <int OFF> __device__ __forceinline__ u32x4 pp_lds_read16(uint32_t addr) {
+    u32x4 d;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+    return d;
+}
+
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int EPI, bool RES, int BN>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ A,
+                                                       const u16* __restrict__ B, const u16* __restrict__ bias,
+                                                       const u16* __restrict__ Rsd, int M, int N, int K, int lda, int ldb,
+                                                       int ldc, int tiles_m, int tiles_n, int group_m, EpiExtra ex) {
+    typedef PP<BN> P;
+    constexpr int MI = P::MI;
+    typedef typename Mfma<T>::frag frag;
+    __shared__ __attribute__((aligned(16))) char smem[P::LDS];  // the ONLY LDS object of the kernel
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m, tiles_n, group_m, tm, tn);
+    const int bm = tm * P::BM, bn = tn * BN;
+    const int wr = wave / P::WAVES_N, wc = wave % P::WAVES_N;
+    const int frow = lane & 15, fq = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+
+    // ---- global -> LDS staging: instruction i of a tile covers rows i*64 + wave*8 + (lane>>3), LDS chunk lane&7
+    uint32_t goffA[P::NLA], goffB[P::NLB];
+    {
+        const int rl = wave * 8 + (lane >> 3), cl = lane & 7;
+#pragma unroll
+        for (int i = 0; i < P::NLA; ++i) {
+            const int r = i * 64 + rl;
+            const int gr = min(bm + r, M - 1);  // edge tiles re-read the last row (never stored)
+            goffA[i] = (uint32_t)gr * (uint32_t)(lda * 2) + (uint32_t)((cl ^ ((r >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < P::NLB; ++i) {
+            const int r = i * 64 + rl;
+            const int gr = min(bn + r, N - 1);
+            goffB[i] = (uint32_t)gr * (uint32_t)(ldb * 2) + (uint32_t)((cl ^ ((r >> 1) & 7)) << 4);
+        }
+    }
+    auto issue = [&](int t, int stage) {  // this wave's rows of K-tile t
+        const char* ag = (const char*)A + (size_t)t * P::ROWB;
+        const char* bg = (const char*)B + (size_t)t * P::ROWB;
+        char* la = smem + stage * P::STAGE + wave * 8 * P::ROWB;  // wave-uniform; HW adds lane*16
+        char* lb = la + P::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < P::NLA; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(ag + goffA[i]), (lds_void*)(la + i * 64 * P::ROWB), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < P::NLB; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(bg + goffB[i]), (lds_void*)(lb + i * 64 * P::ROWB), 16, 0, 0);
+    };
+
+    // ---- fragment reads: byte address row*128 + ((k-chunk) ^ ((row>>1)&7))*16; steps of 16 rows keep the swizzle term, so they
+    // are immediate offsets of the ds_read
+    const uint32_t sw = (uint32_t)((frow >> 1) & 7);
+    const uint32_t arow = (uint32_t)((wr * P::WM + frow) * P::ROWB);
+    const uint32_t brow = (uint32_t)(P::A_BYTES + (wc * 64 + frow) * P::ROWB);
+    u32x4 fa[2][MI], fb[2][4];  // [k-half][16-row block]: the whole K-tile's operands of this wave
+    auto read_frags = [&](int stage) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const uint32_t ch = ((((uint32_t)(kk * 4 + fq)) ^ sw) << 4);
+            const uint32_t ba = lds0 + stage * P::STAGE + brow + ch;
+            const uint32_t aa = lds0 + stage * P::STAGE + arow + ch;
+            fb[kk][0] = pp_lds_read16<0 * 2048>(ba);
+            fb[kk][1] = pp_lds_read16<1 * 2048>(ba);
+            fb[kk][2] = pp_lds_read16<2 * 2048>(ba);
+            fb[kk][3] = pp_lds_read16<3 * 2048>(ba);
+            static_for<0, MI>([&](auto mi) { fa[kk][mi.value] = pp_lds_read16<mi.value * 2048>(aa); });
+        }
+    };
+
+    f32x4 acc[4][MI];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[ni][mi] = Mfma<T>::run(__builtin_bit_cast(frag, fb[kk][ni]), __builtin_bit_cast(frag, fa[kk][mi]), acc[ni][mi]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nt = K / 64;
+    // ---- prologue: tiles 0 and 1 by everyone; tile 0 visible after the barrier
+    issue(0, 0);
+    if (nt > 1) {
+        issue(1, 1);
+        PP_WAIT(P::NL, 15);
+    } else {
+        PP_WAIT(0, 15);
+    }
+    pp_barrier();
+    if (wave < 4) {
+        // ================= group 0: compute tile t in phase 2t, load in phase 2t+1
+        read_frags(0);
+        PP_WAIT(63, 0);
+        for (int t = 0; t < nt; ++t) {
+            compute();
+            // my DMA share of tile t+1 (issued in phase 2t-1, or in the prologue) has landed: the barrier publishes it
+            PP_WAIT(0, 15);
+            pp_barrier();                                   // end of phase 2t
+            if (t + 1 >= nt) break;                         // nothing left to load: straight to the epilogue (LDS is free:
+                                                            // group 1 finished its last fragment reads before this barrier)
+            if (t + 2 < nt) issue(t + 2, t & 1);            // stage t&1: tile t was last read in phase 2t (group 1), done
+            read_frags((t + 1) & 1);                        // tile t+1: both groups' DMA drained before the barrier above
+            PP_WAIT(63, 0);                                 // fragments in registers; the DMA just issued stays in flight
+            pp_barrier();                                   // end of phase 2t+1
+        }
+    } else {
+        // ================= group 1: load tile t in phase 2t, compute it in phase 2t+1
+        for (int t = 0; t < nt; ++t) {
+            if (t >= 1 && t + 1 < nt) issue(t + 1, (t + 1) & 1);  // stage of tile t-1: last read in phase 2t-2 (by this group)
+            read_frags(t & 1);
+            PP_WAIT(0, 0);                                  // fragments in registers AND my DMA share of tile t+1 landed:
+            pp_barrier();                                   // end of phase 2t - group 0 reads tile t+1 right after it
+            compute();
+            if (t + 1 < nt) pp_barrier();                   // end of phase 2t+1
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue (coalesced through a wave-private LDS region: MI*16 rows x 128 B).  Group 0 starts it one phase before
+    // group 1, whose last phase computes from registers; nobody touches the stages any more.
+    epilogue_staged<T, EPI, RES, MI>(acc, smem + wave * (MI * 16 * 128), bm + wr * P::WM, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd,
+                                     lane, ex);
+}
+
+template <typename T, int EPI, int BN>
+static int launch_pp(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
+                     int lda, int ldb, int ldc, hipStream_t st, const EpiExtra& ex) {
+    typedef PP<BN> P;
+    const int tiles_m = (M + P::BM - 1) / P::BM, tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int group_m = (nwg / 8) / tiles_n;  // one XCD's run of tiles spans whole tile-rows when it can
+    group_m = group_m < 1 ? 1 : (group_m > 8 ? 8 : group_m);
+    dim3 grid(nwg), block(512);
+    // (the rotary epilogue carries its tables in the aux / residual slots: never a residual add)
+    if (EPI != MM_EPI_BIAS_ROTARY && (epi_is_bwd(EPI) || residual)) {
+        if constexpr (EPI != MM_EPI_BIAS_ROTARY)
+            gemm_nt_pp_k<T, EPI, true, BN><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
+                                                                   (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, group_m, ex);
+    } else if constexpr (!epi_is_bwd(EPI)) {
+        gemm_nt_pp_k<T, EPI, false, BN><<<grid, block, 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
+                                                                (const u16*)residual, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, group_m, ex);
+    }
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
+template <typename T, int BN>
+static int launch_pp_epi(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N,
+                         int K, int lda, int ldb, int ldc, int epilogue, hipStream_t st, const EpiExtra& ex) {
+    switch (epilogue) {
+        case MM_EPI_BIAS_ROTARY: return launch_pp<T, MM_EPI_BIAS_ROTARY, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_NONE: return launch_pp<T, MM_EPI_NONE, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_BIAS: return launch_pp<T, MM_EPI_BIAS, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_BIAS_GELU_TANH: return launch_pp<T, MM_EPI_BIAS_GELU_TANH, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_BIAS_GELU_ERF: return launch_pp<T, MM_EPI_BIAS_GELU_ERF, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_BIAS_RELU: return launch_pp<T, MM_EPI_BIAS_RELU, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_RELU_BWD: return launch_pp<T, MM_EPI_RELU_BWD, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        case MM_EPI_GELU_TANH_BWD: return launch_pp<T, MM_EPI_GELU_TANH_BWD, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+        default: return launch_pp<T, MM_EPI_GELU_ERF_BWD, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
+    }
+}
+
+// Shape policy (0 = this kernel does not take the problem, else the tile width BN).  MM_GEMMPP: developer switch, 256 / 128 force
+// that tile when legal, -1 = never.
+int gemm_pp_tile(int M, int N, int K, int lda, int ldb) {
+    int force = 0;
+    if (const char* e = getenv("MM_GEMMPP")) force = atoi(e);
+    if (force < 0 || M < 256 || N < 128 || K < 128) return 0;
+    // staging uses 32-bit byte offsets from the operand base
+    if ((size_t)M * (size_t)lda * 2 >= (1ull << 32) || (size_t)N * (size_t)ldb * 2 >= (1ull << 32)) return 0;
+    if (force == 256 || force == 128) return (force == 256 && N < 256) ? 128 : force;
+    // Measured at M = 8192 on one MI355X (us; tools/ab_gemm.py, same process): N=4096 K=1024 bias-GeLU: 128x128 kernel 87-93,
+    // gemm256.hip 78-80, this kernel 256x256 68-70, 256x128 88-98; N=3072 K=1024: 52.5 / 57 / 50.6 / 55.8; N=1024 K=4096:
+    // 62 / 88 / 75 / 66.5; N=1024 K=1024: 19 / 28 / 24 / 20; N=50304 K=1024: 986 / 807 / 806 / 1116.  So: 256x256 tiles from
+    // 1.5 rounds of the 256 CUs up; the N = h class (128 tiles of 256x256) stays on the 128x128 kernel, which two workgroups
+    // per CU keep ahead of the 256x128 variant here.
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    return t256 >= 384 ? 256 : 0;
+}
+
+int gemm_pp_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
+                int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st, const EpiExtra& ex) {
+    const int bn = gemm_pp_tile(M, N, K, lda, ldb);
+    if (bn == 0) return 1;
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        if (bn == 256) return launch_pp_epi<T, 256>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, st, ex);
+        return launch_pp_epi<T, 128>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, st, ex);
+    });
+}
+
+}  // namespace mm

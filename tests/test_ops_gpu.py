@@ -303,17 +303,30 @@ def test_gemm_exact_small_integers(ops, cuda_device):
     assert torch.equal(out.float().cpu(), ref.bfloat16().float())
 
 
+GEMM_KINDS = {  # developer switches of the dispatch (csrc/gemm.hip): which MFMA kernel takes every legal shape
+    0: {},                                                # the library's own shape policy
+    -1: {"MM_GEMMPP": "-1", "MM_GEMM256": "-1"},          # the 128x128 kernel (gemm.hip)
+    1: {"MM_GEMMPP": "-1", "MM_GEMM256": "1"},            # the earlier pipelined 256x256 kernel (gemm256.hip)
+    2: {"MM_GEMMPP": "256"},                              # the ping-pong kernel, 256x256 tiles (gemm_pp.hip)
+    3: {"MM_GEMMPP": "128"},                              # the ping-pong kernel, 256x128 tiles
+}
+
+
 @pytest.fixture
 def force_gemm256():
-    """MM_GEMM256 = 1 forces the 256x256 kernel of gemm256.hip for every legal shape, -1 switches it off."""
+    """Select the GEMM kernel by GEMM_KINDS key for the duration of a test."""
     def setv(v):
-        os.environ["MM_GEMM256"] = str(v)
+        for k in ("MM_GEMMPP", "MM_GEMM256"):
+            os.environ.pop(k, None)
+        os.environ.update(GEMM_KINDS[v])
     yield setv
-    os.environ.pop("MM_GEMM256", None)
+    for k in ("MM_GEMMPP", "MM_GEMM256"):
+        os.environ.pop(k, None)
 
 
-@pytest.mark.parametrize("variant", [1])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 384, 192), (1000, 1156, 320), (2048, 1024, 1024), (300, 260, 64 * 7)])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 384, 192), (1000, 1156, 320), (2048, 1024, 1024), (300, 260, 64 * 7),
+                                   (256, 128, 64 * 3), (520, 132, 64 * 2)])
 @pytest.mark.parametrize("epi", ["none", "bias", "gelu_tanh", "relu"])
 def test_gemm_nt_256_variants(ops, cuda_device, force_gemm256, variant, M, N, K, epi):
     """The pipelined 256x256 kernel on ragged M / N (N % 8 == 4 included), odd and even K-tile counts, every epilogue + residual;
@@ -339,7 +352,7 @@ def test_gemm_nt_256_variants(ops, cuda_device, force_gemm256, variant, M, N, K,
         assert ((aux.double().cpu() - uref).abs() <= 2.0 ** -7 * uref.abs() + 1e-2).all()
 
 
-@pytest.mark.parametrize("variant", [1])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_gemm_nt_256_exact_integers(ops, cuda_device, force_gemm256, variant):
     """Asymmetric small-integer operands: every product and partial sum is exact, so any misplaced fragment, stale LDS
     stage shows as a wrong integer."""
@@ -351,7 +364,8 @@ def test_gemm_nt_256_exact_integers(ops, cuda_device, force_gemm256, variant):
     assert torch.equal(out.float().cpu(), (a @ b.t()).bfloat16().float())
 
 
-@pytest.mark.parametrize("variant,N,K", [(1, 4096, 1024), (1, 1024, 4096), (1, 3072, 1024)])
+@pytest.mark.parametrize("variant,N,K", [(1, 4096, 1024), (1, 1024, 4096), (1, 3072, 1024), (2, 4096, 1024), (2, 1024, 4096),
+                                         (3, 1024, 4096), (3, 1024, 1024), (3, 3072, 1024), (3, 1024, 3072), (2, 50304, 1024)])
 def test_gemm_nt_256_race_screen(ops, cuda_device, force_gemm256, variant, N, K):
     """The kernel is deterministic, so a read of an LDS stage before its DMA landed (or after it was recycled) shows as a
     run-to-run difference: 30 launches at the benchmark shapes must agree bit for bit, and with the 128x128 kernel to rounding."""
@@ -503,7 +517,8 @@ def test_gemm_tn_exact_integers_and_reproducible(ops, cuda_device):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("M,N,K,force", [(256, 128, 1024, 0), (300, 132, 192, 0), (512, 512, 128, 1), (8192, 128, 1024, 0), (40, 20, 12, 0)])
+@pytest.mark.parametrize("M,N,K,force", [(256, 128, 1024, 0), (300, 132, 192, 0), (512, 512, 128, 1), (8192, 128, 1024, 0), (40, 20, 12, 0),
+                                          (512, 512, 128, 2), (520, 260, 192, 3)])
 @pytest.mark.parametrize("epi", ["relu_bwd", "gelu_tanh_bwd", "gelu_erf_bwd"])
 def test_gemm_nt_backward_epilogues(ops, cuda_device, force_gemm256, dt, M, N, K, force, epi):
     """Data-gradient GEMM fused with the activation backward == the GEMM followed by this library's own elementwise
@@ -609,7 +624,9 @@ def _rot_tables(s, d, dtype, dev, offset=0):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("s,b,np_,d,K,offset,force", [(64, 2, 2, 16, 64, 0, 0), (33, 3, 4, 32, 128, 2, 0), (100, 1, 2, 64, 192, 0, 0),
-                                                      (128, 4, 4, 16, 256, 0, 1), (75, 4, 8, 64, 128, 1, 1), (2048, 4, 16, 16, 1024, 0, 0)])
+                                                      (128, 4, 4, 16, 256, 0, 1), (75, 4, 8, 64, 128, 1, 1), (2048, 4, 16, 16, 1024, 0, 0),
+                                                      (128, 4, 4, 16, 256, 0, 2), (75, 4, 8, 64, 128, 1, 2), (128, 4, 4, 32, 256, 0, 3),
+                                                      (75, 4, 8, 64, 128, 1, 3)])
 def test_gemm_qkv_rotary_epilogue_equals_two_passes(ops, cuda_device, force_gemm256, dt, s, b, np_, d, K, offset, force):
     """mm_gemm_nt_qkv_rotary (rotary embedding as the QKV GEMM's epilogue) is bit-identical to mm_gemm_nt(bias) followed by
     mm_rotary_qk_inplace - both the 128x128 and the 256x256 kernel, ragged row counts, every fused rotary width."""
@@ -622,7 +639,7 @@ def test_gemm_qkv_rotary_epilogue_equals_two_passes(ops, cuda_device, force_gemm
     cos, sin = _rot_tables(s, d, dtype, cuda_device, offset)
     assert ops.qkv_rotary_supported(hn, d, w.size(0), K, s * b, b)
     if force:
-        force_gemm256(1)
+        force_gemm256(force)
     fused = ops.gemm_nt_qkv_rotary(x, w, bias, cos, sin, b, hn, d, offset)
     two = ops.gemm_nt(x, w, bias, 1)
     ops.rotary_qk_inplace(two.view(s, b, np_, 3 * hn), cos, sin, s, b, np_, hn, d, offset)
