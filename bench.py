@@ -117,7 +117,17 @@ def cpu_baseline(cfg, budget_s):
             break
     t_layer = min(times)
     tok_s = (s * b) / (t_layer * cfg["num_layers"])
-    return {"value": round(tok_s, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
+    # BASELINE.md section 3 workload A (BASELINE.json configs[0]): the 19M text-only train step, whole model, on the same cores
+    from oracle import workload_a as WA
+    wl, wt = WA.train_steps(WA.CONFIG_19M, steps=3, budget_s=max(5.0, budget_s * 0.6))
+    wa_step = min(wt[1:]) if len(wt) > 1 else wt[0]
+    workload_a = {"tokens_per_s": round(WA.CONFIG_19M["micro_batch"] * WA.CONFIG_19M["seq_length"] / wa_step, 1),
+                  "s_per_step": round(wa_step, 3), "steps_run": len(wt), "losses": [round(v, 4) for v in wl],
+                  "gflops_per_s": round(WA.flops_per_step(WA.CONFIG_19M) / wa_step / 1e9, 1),
+                  "what": "19M.yml text-only GPT-NeoX train step (L=6 h=512 heads=8 s=2048 micro_batch=4 V=50304, fp32, eager "
+                          "softmax / erf GeLU, Adam) on the CPU oracle stack (oracle/workload_a.py): embedding, 6 layers, final "
+                          "LayerNorm, LM head, masked cross entropy, backward, optimizer step"}
+    return {"value": round(tok_s, 2), "unit": "tokens/s", "cores": threads, "kind": "port", "workload_a": workload_a,
             "sample": "CPU oracle (oracle/neox_layer_oracle.py, fp32 eager torch) of 1 of %d layers fwd+bwd at the full shape "
                       "(s=%d, b=%d, h=%d), best of %d runs = %.3f s/layer, scaled by layers; head/embedding/optimizer excluded"
                       % (cfg["num_layers"], s, b, h, len(times), t_layer)}

@@ -177,6 +177,51 @@ def test_layer_with_adapters_matches_reference_fixture(cuda_device, name):
     assert all(g is None for k, g in grads.items() if "adapter" not in k)
 
 
+def test_full_shape_410m_layer_vs_fp32_oracle(cuda_device):
+    """The assembled magma_pythia_410M layer AT THE BENCH SHAPE (s=2048, b=4, h=1024, 16 heads, GPT-J residual, tanh bias-GeLU,
+    rotary 25 %, adapters on .attention and .mlp, LM frozen: configs/magma_pythia_410M.yml:5-33) against the fp32 CPU oracle on
+    the same bf16-rounded weights and inputs.  Stated tolerance: relative L2 error <= 8e-3 for y and dX (the small reference
+    fixtures sit at 3e-3 for both the HIP layer and the reference's own bf16 run), max |err| <= 2^-5 of the largest value,
+    adapter gradients relative L2 <= 2e-2.  Costs ~10 s of host time."""
+    from multimodal_amd.model import add_adapters
+    h, n, s, b = 1024, 16, 2048, 4
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(410)
+    master = golden_params.master_params(rng, h)
+    x = golden_params.rng_t(rng, (s, b, h)).to(dtype)
+    dy = golden_params.rng_t(rng, (s, b, h)).to(dtype)
+    ad = golden_params.adapter_params(rng, h, h // 8)
+    args = LH.make_neox_args(h, n, dtype, 0.25, True, True, softmax_fusion=True)
+    layer = LH.build_hip_layer(args, master, cuda_device)
+    holder = torch.nn.ModuleList([layer])
+    add_adapters(args, holder, downsample_factor=8, location="mlp")
+    add_adapters(args, holder, downsample_factor=8, location="attention")
+    sd = dict(layer.named_parameters())
+    with torch.no_grad():
+        for k in golden_params.ADAPTER_KEYS:
+            sd[k].copy_(ad[k].to(dtype))
+    for nme, p in layer.named_parameters():
+        p.requires_grad = "adapter" in nme
+    y, dx, grads = LH.run_hip_layer(layer, x, dy, cuda_device)
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+    cfg = O.LayerConfig(h, n, rotary_pct=0.25, gpt_j_residual=True, bias_gelu_fusion=True)
+    p32 = {k: master[k].to(dtype).float() for k in golden_params.PARAM_ORDER}          # frozen LM: no gradients wanted
+    p32.update({k: v.to(dtype).float().requires_grad_(True) for k, v in ad.items()})
+    xin = x.float().requires_grad_(True)
+    y32 = O.layer_forward(cfg, [p32], xin, O.causal_mask(s))
+    y32.backward(dy.float())
+    y32 = y32.detach()
+
+    def rel(a, ref):
+        return float((a.float() - ref).norm() / ref.norm())
+
+    assert rel(y, y32) <= 8e-3 and rel(dx, xin.grad) <= 8e-3, (rel(y, y32), rel(dx, xin.grad))
+    assert float((y.float() - y32).abs().max()) <= 2.0 ** -5 * float(y32.abs().max())
+    assert float((dx.float() - xin.grad).abs().max()) <= 2.0 ** -5 * float(xin.grad.abs().max())
+    for k in golden_params.ADAPTER_KEYS:
+        assert rel(grads[k], p32[k].grad) <= 2e-2, (k, rel(grads[k], p32[k].grad))
+
+
 @pytest.mark.parametrize("dt", ["bf16"])
 def test_stack_loss_curve_on_gpu(cuda_device, dt):
     """20 Adam steps of the 2-layer stack through the HIP layers reproduce the reference's loss curve (stated tolerance:

@@ -153,3 +153,14 @@ def test_neox_layer_config_plumbing_without_gpu():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         layer(torch.zeros(8, 1, 512, dtype=torch.bfloat16), None)
     mpu.destroy_model_parallel()
+
+
+def test_cpu_workload_a_trains():
+    """BASELINE.json configs[0] restated on the oracle (oracle/workload_a.py; bench.py times it at the full 19M shape as
+    cpu_baseline.workload_a): at a reduced shape the initial loss sits at ln(V) and Adam brings it down."""
+    from oracle import workload_a as WA
+    cfg = dict(WA.CONFIG_19M, hidden_size=64, num_attention_heads=2, num_layers=2, seq_length=64, micro_batch=2, vocab=512)
+    losses, times = WA.train_steps(cfg, steps=12, lr=3e-3, fixed_batch=True)   # one batch: the loss must fall
+    assert abs(losses[0] - WA.expected_initial_loss(cfg)) < 0.4   # ln(V) + init noise (the reference logs 11.03 vs ln(50304) = 10.83)
+    assert losses[-1] < losses[0] - 0.05 and len(times) == 12
+    assert WA.flops_per_step(WA.CONFIG_19M) > 2.5e12   # ~2.8 TFLOP per full-shape step

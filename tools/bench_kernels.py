@@ -99,6 +99,33 @@ def bench_small():
         print("%-20s %8.1f us %7.2f TB/s" % (name, t, nbytes / t / 1e6))
 
 
+def bench_softmax():
+    """The standalone scaled_*_softmax kernels at the 410M attention shape: [b*np = 64, s = 2048, s = 2048] bf16.
+    Algorithmic bytes: causal forward 3 * rows * sk (reads the lower triangle = half, writes every element: 1 + 2),
+    masked forward 4 * rows * sk (+ 1 byte per element of mask), backward 6 * rows * sk (grad + y in, grad out)."""
+    nb, s = B * NP, S
+    xs = [rnd(nb, s, s) for _ in range(2)]
+    i = [0]
+
+    def nxt():
+        i[0] += 1
+        return xs[i[0] % 2]
+    el = nb * s * s
+    t = timeit(lambda: ops.softmax_causal_fwd(nxt(), 1.0), n=20, warm=4)
+    print("softmax_causal_fwd  %8.1f us  %6.2f TB/s (3 B/element)" % (t, 3.0 * el / t / 1e6))
+    y = ops.softmax_causal_fwd(xs[0], 1.0)
+    gs = [rnd(nb, s, s) for _ in range(2)]
+    t = timeit(lambda: ops.softmax_causal_bwd(gs[i[0] % 2], y, 1.0), n=20, warm=4)
+    print("softmax_causal_bwd  %8.1f us  %6.2f TB/s (6 B/element; the causal kernel touches the lower triangle only: 3)" % (t, 6.0 * el / t / 1e6))
+    mask = torch.triu(torch.ones(s, s, dtype=torch.bool, device=DEV), 1).view(1, 1, s, s)
+    x4 = [x.view(B, NP, s, s) for x in xs]
+    t = timeit(lambda: ops.softmax_masked_fwd(x4[i[0] % 2], mask, 1.0), n=20, warm=4)
+    print("softmax_masked_fwd  %8.1f us  %6.2f TB/s (4 B/element + the shared mask)" % (t, 4.0 * el / t / 1e6))
+    y4 = ops.softmax_masked_fwd(x4[0], mask, 1.0)
+    t = timeit(lambda: ops.softmax_masked_bwd(gs[i[0] % 2].view(B, NP, s, s), y4, 1.0), n=20, warm=4)
+    print("softmax_masked_bwd  %8.1f us  %6.2f TB/s (6 B/element)" % (t, 6.0 * el / t / 1e6))
+
+
 def bench_adapter():
     r = H // 8
     o, g = rnd(T, H), rnd(T, H)
@@ -117,7 +144,7 @@ def bench_adapter():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attn", "gemm", "tn", "small", "adapter"]
+    which = sys.argv[1:] or ["attn", "gemm", "tn", "small", "adapter", "softmax"]
     print("device:", torch.cuda.get_device_name(0))
     for w in which:
-        {"attn": bench_attn, "gemm": bench_gemm, "tn": bench_tn, "small": bench_small, "adapter": bench_adapter}[w]()
+        {"attn": bench_attn, "gemm": bench_gemm, "tn": bench_tn, "small": bench_small, "adapter": bench_adapter, "softmax": bench_softmax}[w]()
