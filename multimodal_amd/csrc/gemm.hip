@@ -58,10 +58,13 @@ __global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* _
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = K / BK;
+    // the weight matrix on its way into the Infinity Cache (first 512 workgroups of the launch; gemm_common.h)
+    const u32x2 warm = touch_weight(B, N, K, ldb, blockIdx.x, min((int)gridDim.x, 512), tid, 256);
     // stage s: A tile at smem + s*2*TILE_BYTES, B tile right behind it
     stage_tile<T>(smem, A, lda, bm, M, 0, wave, lane);
     stage_tile<T>(smem + TILE_BYTES, B, ldb, bn, N, 0, wave, lane);
     __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
+    asm volatile("" ::"v"(warm[0]), "v"(warm[1]));
 
     // per-lane fragment read offsets (bytes) inside a tile, for kk = 0; kk = 1 flips chunk bit 2
     const int frow = lane & 15, fq = lane >> 4;

@@ -52,6 +52,35 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
     tn = (bid % group_sz) / gm;
 }
 
+// Warm the Infinity Cache with the B operand (a weight matrix, [N, K] rows of K 16-bit values).  A weight is read once per
+// direction per step and the step's working set (~1 GB of weights + activations per pass) is far beyond the 256 MiB cache, so
+// every GEMM finds its weight in HBM: measured on the h->4h GEMM (M=8192 N=4096 K=1024, tools/ab_gemm_cold2.py, medians) all
+// operands cached 71.6 us, weight cold 79.8, everything cold 90.5, everything cold but A and W read once just before 73.7 -
+// the K loop keeps only one or two 64-deep tiles in flight (LDS is full), enough for the cache's latency, not for HBM's.
+// So the first `nblk` workgroups of a launch read one dword of every 128-byte line of B between them, before their first tile
+// fetch: the whole matrix is on its way into the cache while the first tiles start, at the cost of one or two loads per
+// thread.  Returns the loads' destination registers: the caller must keep them live (an empty asm use) until its first vmcnt
+// wait has passed, so that they are not handed to other code while a load is in flight.
+__device__ __forceinline__ u32x2 touch_weight(const u16* __restrict__ B, int N, int K, int ldb, int bid, int nblk, int tid, int nthr) {
+    u32x2 d = {0u, 0u};
+    const int lines_per_row = (K * 2 + 127) >> 7;
+    const long total = (long)N * lines_per_row;
+    const long stride = (long)nblk * nthr;
+    if (bid >= nblk || total > 2 * stride) return d;  // at most two lines per thread (32 MiB at 256 x 512 threads)
+    // inline asm: the compiler must not put a wait on these (it would stall the prologue for an HBM round trip); the loads
+    // complete in order ahead of the tile fetches, whose counted wait covers them
+    const long L0 = (long)bid * nthr + tid, L1 = L0 + stride;
+    if (L0 < total) {
+        const u16* p = B + (size_t)(L0 / lines_per_row) * ldb + min((int)(L0 % lines_per_row) * 64, K - 2);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(d[0]) : "v"(p));
+    }
+    if (L1 < total) {
+        const u16* p = B + (size_t)(L1 / lines_per_row) * ldb + min((int)(L1 % lines_per_row) * 64, K - 2);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(d[1]) : "v"(p));
+    }
+    return d;
+}
+
 // bias values of 4 consecutive columns
 template <typename T> __device__ __forceinline__ void load_bias4(float (&bv)[4], const u16* __restrict__ bias, int n0) {
     const u32x2 braw = *reinterpret_cast<const u32x2*>(bias + n0);
