@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* _
                                                      const u16* __restrict__ B, const u16* __restrict__ bias,
                                                      const u16* __restrict__ Rsd, int M, int N, int K, int lda, int ldb,
                                                      int ldc, int tiles_m, int tiles_n, EpiExtra ex) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES + 4 * 256];  // stages + the warming loads' dump area
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
     int tm, tn;
@@ -59,12 +59,11 @@ __global__ __launch_bounds__(256) void gemm_nt_128_k(u16* __restrict__ C, u16* _
 
     const int nt = K / BK;
     // the weight matrix on its way into the Infinity Cache (first 512 workgroups of the launch; gemm_common.h)
-    const u32x2 warm = touch_weight(B, N, K, ldb, blockIdx.x, min((int)gridDim.x, 512), tid, 256);
+    touch_weight(B, N, K, ldb, blockIdx.x, min((int)gridDim.x, 512), tid, 256, smem + 2 * 2 * TILE_BYTES + wave * 256);
     // stage s: A tile at smem + s*2*TILE_BYTES, B tile right behind it
     stage_tile<T>(smem, A, lda, bm, M, 0, wave, lane);
     stage_tile<T>(smem + TILE_BYTES, B, ldb, bn, N, 0, wave, lane);
     __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
-    asm volatile("" ::"v"(warm[0]), "v"(warm[1]));
 
     // per-lane fragment read offsets (bytes) inside a tile, for kk = 0; kk = 1 flips chunk bit 2
     const int frow = lane & 15, fq = lane >> 4;

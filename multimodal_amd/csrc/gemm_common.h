@@ -59,26 +59,38 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 // the K loop keeps only one or two 64-deep tiles in flight (LDS is full), enough for the cache's latency, not for HBM's.
 // So the first `nblk` workgroups of a launch read one dword of every 128-byte line of B between them, before their first tile
 // fetch: the whole matrix is on its way into the cache while the first tiles start, at the cost of one or two loads per
-// thread.  Returns the loads' destination registers: the caller must keep them live (an empty asm use) until its first vmcnt
-// wait has passed, so that they are not handed to other code while a load is in flight.
-__device__ __forceinline__ u32x2 touch_weight(const u16* __restrict__ B, int N, int K, int ldb, int bid, int nblk, int tid, int nthr) {
-    u32x2 d = {0u, 0u};
+// thread (weight cold 79.8 -> 73.2 us, everything cold 90.5 -> 82.2).
+// The loads are LDS-DMA into a 256-byte per-wave dump area (`dump`, wave-uniform): a load into a REGISTER would have to keep
+// that register reserved until it lands, which plain HIP cannot promise - under register pressure the compiler moves or
+// spills the (to it, already valid) value and hands the register to other code, and the late load then overwrites a live
+// address (it did: GPU memory fault).  Nothing ever reads the dump area.  Out-of-range lanes re-read line 0.
+__device__ __forceinline__ void touch_weight(const u16* __restrict__ B, int N, int K, int ldb, int bid, int nblk, int tid, int nthr,
+                                             char* dump) {
     const int lines_per_row = (K * 2 + 127) >> 7;
-    const long total = (long)N * lines_per_row;
-    const long stride = (long)nblk * nthr;
-    if (bid >= nblk || total > 2 * stride) return d;  // at most two lines per thread (32 MiB at 256 x 512 threads)
-    // inline asm: the compiler must not put a wait on these (it would stall the prologue for an HBM round trip); the loads
-    // complete in order ahead of the tile fetches, whose counted wait covers them
-    const long L0 = (long)bid * nthr + tid, L1 = L0 + stride;
-    if (L0 < total) {
-        const u16* p = B + (size_t)(L0 / lines_per_row) * ldb + min((int)(L0 % lines_per_row) * 64, K - 2);
-        asm volatile("global_load_dword %0, %1, off" : "=v"(d[0]) : "v"(p));
+    const long total_l = (long)N * lines_per_row;
+    const int stride = nblk * nthr;
+    if (bid >= nblk || total_l > 2l * stride) return;  // (workgroup-uniform) at most two lines per thread: 32 MiB at 256 x 512 threads
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int total = (int)total_l;
+        int L = bid * nthr + tid + i * stride;
+        if (i == 1 && total <= stride) break;       // uniform
+        if (L >= total) L = 0;
+        const u16* p = B + (size_t)(L / lines_per_row) * ldb + min((int)(L % lines_per_row) * 64, K - 2);
+        __builtin_amdgcn_global_load_lds((const void*)p, (lds_void*)dump, 4, 0, 0);
     }
-    if (L1 < total) {
-        const u16* p = B + (size_t)(L1 / lines_per_row) * ldb + min((int)(L1 % lines_per_row) * 64, K - 2);
-        asm volatile("global_load_dword %0, %1, off" : "=v"(d[1]) : "v"(p));
+}
+
+// The same for the second INPUT of a backward epilogue (the saved forward tensor in the residual slot: 64 MiB of pre-activations
+// written one forward pass earlier, i.e. in HBM): a 512-thread workgroup reads one dword of every 128-byte line of its own
+// 256 x 256 tile (1024 lines, two per thread) before its first tile fetch, so that the epilogue finds the tile in the cache.
+__device__ __forceinline__ void touch_tile256(const u16* __restrict__ X, int ld, int m0, int n0, int M, int N, int tid, char* dump) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = tid + 512 * i;                  // line id inside the tile: row L >> 2, 128-byte piece L & 3
+        const int m = min(m0 + (L >> 2), M - 1), n = min(n0 + (L & 3) * 64, N - 2);
+        __builtin_amdgcn_global_load_lds((const void*)(X + (size_t)m * ld + n), (lds_void*)dump, 4, 0, 0);
     }
-    return d;
 }
 
 // bias values of 4 consecutive columns

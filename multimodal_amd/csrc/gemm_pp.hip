@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
     typedef PP<BN> P;
     constexpr int MI = P::MI;
     typedef typename Mfma<T>::frag frag;
-    __shared__ __attribute__((aligned(16))) char smem[P::LDS];  // the ONLY LDS object of the kernel
+    __shared__ __attribute__((aligned(16))) char smem[P::LDS + 8 * 256];  // the ONLY LDS object of the kernel (+ the warming loads' dump area)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int tm, tn;
     tile_coords(blockIdx.x, tiles_m, tiles_n, group_m, tm, tn);
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
 
     const int nt = K / 64;
     // the weight matrix on its way into the Infinity Cache (first 256 workgroups of the launch; gemm_common.h)
-    const u32x2 warm = touch_weight(B, N, K, ldb, blockIdx.x, min((int)gridDim.x, 256), tid, 512);
+    touch_weight(B, N, K, ldb, blockIdx.x, min((int)gridDim.x, 256), tid, 512, smem + P::LDS + wave * 256);
+    if constexpr (BN == 256 && epi_is_bwd(EPI)) touch_tile256(Rsd, ldc, bm, bn, M, N, tid, smem + P::LDS + wave * 256);
     // ---- prologue: tiles 0 and 1 by everyone; tile 0 visible after the barrier
     issue(0, 0);
     if (nt > 1) {
@@ -150,7 +151,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
         PP_WAIT(0, 15);
     }
     pp_barrier();
-    asm volatile("" ::"v"(warm[0]), "v"(warm[1]));  // the warming loads' destination stays reserved until the wait above has covered them
     if (wave < 4) {
         // ================= group 0: compute tile t in phase 2t, load in phase 2t+1
         read_frags(0);

@@ -7,8 +7,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_amd import _lib
 from tools.bench_kernels import rnd, T, H, DEV
-M, N, K = T, 4 * H, H
-R = 16
+M, N, K = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (T, 4 * H, H)
+EPI = int(sys.argv[4]) if len(sys.argv) > 4 else _lib.EPI_BIAS_GELU_TANH
+R = max(2, min(16, (3 << 30) // (2 * (M * K + N * K + 2 * M * N))))
 a = [rnd(M, K) for _ in range(R)]
 w = [rnd(N, K, scale=0.02) for _ in range(R)]
 bias = rnd(N)
@@ -34,11 +35,12 @@ for rnd_i in range(12):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             _lib.check(lib.mm_gemm_nt(outs[j % ro].data_ptr(), auxs[j % ro].data_ptr(), a[j % ra].data_ptr(), w[j % rw].data_ptr(),
-                                      bias.data_ptr(), None, M, N, K, K, K, N, _lib.EPI_BIAS_GELU_TANH, 0, st))
+                                      bias.data_ptr(), None, M, N, K, K, K, N, EPI, 0, st))
             e1.record()
             torch.cuda.synchronize()
             if rnd_i >= 2:
                 times[name].append(e0.elapsed_time(e1) * 1e3)
+print("M=%d N=%d K=%d epilogue %d, %d rotating sets" % (M, N, K, EPI, R))
 for name, *_ in configs:
     v = sorted(times[name])
     print("%-30s median %.1f us   p10 %.1f   p90 %.1f   (%d launches)" % (name, statistics.median(v), v[len(v) // 10], v[-len(v) // 10 - 1], len(v)))
