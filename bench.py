@@ -52,10 +52,13 @@ def roofline_from_probe(cfg, probe, tp=1):
     T = cfg["micro_batch"] * cfg["seq_length"]
     h = cfg["hidden_size"]
     N = 4 * h // tp
-    ms = sorted(a.elapsed_time(b) for a, b, M, Nn, K in probe["events"] if (M, Nn, K) == (T, N, h))
-    if not ms:
-        raise RuntimeError("bench.py: no launch of the roofline kernel (M=%d N=%d K=%d, epilogue %d) was seen by the event probe"
-                           % (T, N, h, probe["epilogue"]))
+    # (with tensor parallelism the stack walks the layers in sub-batches - mpu/overlap.py - so a launch covers T / chunks rows)
+    hits = [(a.elapsed_time(b), M) for a, b, M, Nn, K in probe["events"] if (Nn, K) == (N, h)]
+    if not hits:
+        raise RuntimeError("bench.py: no launch of the roofline kernel (N=%d K=%d, epilogue %d) was seen by the event probe"
+                           % (N, h, probe["epilogue"]))
+    T = max(M for _, M in hits)
+    ms = sorted(t for t, M in hits if M == T)
     avg_ms = sum(ms) / len(ms)
     flops = 2.0 * T * h * N
     achieved = flops / (avg_ms * 1e-3) / 1e12
@@ -311,7 +314,7 @@ def main():
                        "launches on one stream: %.3f ms/step (the roofline kernel's HIP events are recorded in those)"
                        % (" + clip + Adam" if world == 1 else "; all-reduce + clip + Adam follow eagerly", a.steps, a.steps,
                           dt_eager / a.steps * 1e3)) if dt_graph is not None else
-                      ("eager launches" + (" (graph capture failed: %s)" % graph_err if graph_err else "")),
+                      ("eager launches" + ((" (%s)" if a.tp > 1 else " (graph capture failed: %s)") % graph_err if graph_err else "")),
             "eager_ms_per_step": round(dt_eager / a.steps * 1e3, 3),
             "roofline": roof,
         }

@@ -53,6 +53,11 @@ CONFIGS = {
                        gpt_j_residual=True, bias_gelu_fusion=True, scaled_upper_triang_masked_softmax_fusion=True,
                        add_adapters=True, adapter_downsample_factor=8, freeze_lm=True, micro_batch=2,
                        padded_vocab_size=1024, encoder_out_dim=64, prefix_len=1, image_embed_dropout_prob=0.1),
+    # the summit-1-3B recipe (head size 128, sequential residual, erf GeLU, full rotary, everything trainable) at test size
+    "tiny_1_3B": dict(hidden_size=256, num_attention_heads=2, num_layers=2, seq_length=128, rotary_pct=1.0,
+                      gpt_j_residual=False, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
+                      add_adapters=False, adapter_downsample_factor=8, freeze_lm=False, micro_batch=4,
+                      padded_vocab_size=1024, encoder_out_dim=64, prefix_len=1, image_embed_dropout_prob=0.0),
     "tiny": dict(hidden_size=256, num_attention_heads=4, num_layers=2, seq_length=256, rotary_pct=0.25,
                  gpt_j_residual=True, bias_gelu_fusion=True, scaled_upper_triang_masked_softmax_fusion=True,
                  add_adapters=False, adapter_downsample_factor=8, freeze_lm=False, micro_batch=2,
@@ -61,6 +66,8 @@ CONFIGS = {
 
 
 def neox_args_for(cfg, dtype=torch.bfloat16, tp=1):
+    """cfg["use_cpu_initialization"] (default False): build every sharded weight from its full master on the host and keep this
+    rank's slices (mpu/layers.py:53-93) - the same seed then gives the same model at every tensor-parallel degree."""
     return SimpleNamespace(
         hidden_size=cfg["hidden_size"], num_attention_heads=cfg["num_attention_heads"], num_layers=cfg["num_layers"],
         seq_length=cfg["seq_length"], precision={torch.bfloat16: "bfloat16", torch.float16: "fp16"}[dtype],
@@ -69,7 +76,8 @@ def neox_args_for(cfg, dtype=torch.bfloat16, tp=1):
         scaled_upper_triang_masked_softmax_fusion=cfg["scaled_upper_triang_masked_softmax_fusion"],
         scaled_masked_softmax_fusion=False, apply_query_key_layer_scaling=False, attention_softmax_in_fp32=False,
         attention_dropout=0.0, hidden_dropout=0.0, gpt_j_residual=cfg["gpt_j_residual"], gpt_j_tied=False,
-        attention_config=["global"] * cfg["num_layers"], use_mup=False, use_cpu_initialization=False,
+        attention_config=["global"] * cfg["num_layers"], use_mup=False,
+        use_cpu_initialization=bool(cfg.get("use_cpu_initialization", False)),
         model_parallel_size=tp, fp32_allreduce=False, onnx_safe=False)
 
 
@@ -145,6 +153,16 @@ class MagmaStack(nn.Module):
             return x
         return run
 
+    def _head_loss_parts(self, x, labels, loss_mask):
+        """(sum of masked token losses, number of unmasked tokens) of one (sub-)batch: final LayerNorm, LM head
+        (transformer.py:816-839) and the vocabulary-parallel loss over the TP group (gpt2_model.py:52-70 ->
+        mpu/cross_entropy.py:27-117: three [b, s] exchanges; each rank's softmax covers its own vocabulary partition)."""
+        x = self.final_norm(x.transpose(0, 1).contiguous())
+        logits, _ = self.final_linear(x)  # [b, s, V/p]: gather_output=False (transformer.py:151-161)
+        losses = mpu.vocab_parallel_cross_entropy(logits, labels)
+        lm = loss_mask.reshape(-1).float()
+        return torch.sum(losses.reshape(-1) * lm), lm.sum()
+
     def forward(self, enc_out, tokens, labels, loss_mask):
         """enc_out [b, P, enc_dim] | None, tokens [b, s] int64, labels [b, s], loss_mask [b, s] float -> scalar loss."""
         b, s = tokens.shape
@@ -152,27 +170,33 @@ class MagmaStack(nn.Module):
         # gather + [prefix | text[:, :s-P]] + [b,s,h] -> [s,b,h] in one kernel
         x = Fn.embed_prefix(pre, self.word_embeddings.weight, tokens)
         mask = self.attention_mask(s, x.device)
-        for start, stop, recompute in checkpoint_policy(len(self.layers), self.cfg.get("checkpoint_activations", False),
-                                                        self.cfg.get("checkpoint_num_layers", 1)):
+        tp = mpu.get_model_parallel_world_size()
+        chunks = int(self.cfg.get("tp_overlap_chunks", 2 if tp > 1 else 1))
+        recompute = self.cfg.get("checkpoint_activations", False)
+        if tp > 1 and chunks > 1 and b % chunks == 0 and not recompute:
+            # tensor parallel: sub-batches walk the layers in lock step on separate streams, so that each sub-batch's
+            # all-reduces overlap the other's GEMMs / attention (mpu/overlap.py); bit-identical to the unsplit run
+            xs = mpu.split_batch(x, chunks, dim=1)
+            lbl, lms = torch.chunk(labels, chunks, dim=0), torch.chunk(loss_mask, chunks, dim=0)
+            stages = [(lambda t, layer=layer: layer(t, mask)) for layer in self.layers]
+            parts = mpu.run_interleaved(stages, xs, finish=lambda i, t: self._head_loss_parts(t, lbl[i], lms[i]))
+            return sum(p[0] for p in parts) / sum(p[1] for p in parts)
+        for start, stop, recompute in checkpoint_policy(len(self.layers), recompute, self.cfg.get("checkpoint_num_layers", 1)):
             if recompute and torch.is_grad_enabled():  # gpt2_model.py:123-132
                 if not x.requires_grad:
                     x = x.detach().requires_grad_(True)  # the re-entrant recompute needs a differentiable input
                 x = mpu.checkpoint(self._run_layers(start, stop), x, mask)
             else:
                 x = self._run_layers(start, stop)(x, mask)
+        if tp > 1:
+            total, count = self._head_loss_parts(x, labels, loss_mask)
+            return total / count
         x = x.transpose(0, 1).contiguous()
         x = self.final_norm(x)
         w = self.final_linear.weight
-        if (self.cfg.get("fused_head_loss", True) and torch.is_grad_enabled() and mpu.get_model_parallel_world_size() == 1
-                and Fn.lm_head_loss_supported(x, w)):
+        if self.cfg.get("fused_head_loss", True) and torch.is_grad_enabled() and Fn.lm_head_loss_supported(x, w):
             return Fn.lm_head_loss(x, w, labels, loss_mask)  # head + loss, logits read once
-        logits, _ = self.final_linear(x)  # [b, s, V/p]: gather_output=False (transformer.py:151-161)
-        if mpu.get_model_parallel_world_size() > 1:
-            # vocabulary-parallel loss over the TP group (gpt2_model.py:52-70 -> mpu/cross_entropy.py:27-117): three [b, s]
-            # exchanges; each rank's softmax runs over its own partition only
-            losses = mpu.vocab_parallel_cross_entropy(logits, labels)
-            lm = loss_mask.reshape(-1).float()
-            return torch.sum(losses.reshape(-1) * lm) / lm.sum()
+        logits, _ = self.final_linear(x)
         return Fn.masked_cross_entropy(logits, labels, loss_mask)
 
 

@@ -13,3 +13,4 @@ from .random import checkpoint, get_cuda_rng_tracker, model_parallel_cuda_manual
 from .utils import VocabUtility, divide, ensure_divisibility, split_tensor_along_last_dim  # noqa: F401
 from .data_parallel import allreduce_gradients  # noqa: F401
 from .cross_entropy import vocab_parallel_cross_entropy  # noqa: F401
+from .overlap import run_interleaved, split_batch  # noqa: F401

@@ -15,6 +15,7 @@ import torch
 
 from .. import ops
 from .initialize import get_model_parallel_group, get_model_parallel_rank, get_model_parallel_world_size
+from .mappings import _all_reduce
 from .utils import VocabUtility
 
 
@@ -35,10 +36,10 @@ class _VocabParallelCrossEntropy(torch.autograd.Function):
             group = get_model_parallel_group()
             predicted = lse_local - loss_local          # x[target] on the owning rank, 0 elsewhere
             m = lse_local.clone()
-            torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX, group=group)
+            _all_reduce(m, group, torch.distributed.ReduceOp.MAX)
             sum_exp = torch.exp(lse_local - m)
-            torch.distributed.all_reduce(sum_exp, op=torch.distributed.ReduceOp.SUM, group=group)
-            torch.distributed.all_reduce(predicted, op=torch.distributed.ReduceOp.SUM, group=group)
+            _all_reduce(sum_exp, group)
+            _all_reduce(predicted, group)
             lse = m + torch.log(sum_exp)
             loss = lse - predicted
         ctx.save_for_backward(logits2d, local, lse)

@@ -11,6 +11,19 @@ from .initialize import (get_fp32_allreduce, get_model_parallel_group, get_model
 from .utils import split_tensor_along_last_dim
 
 
+def _all_reduce(t, group, op=None):
+    """RCCL ("nccl") takes the device tensor as it is.  gloo - the transport of the CPU tests and of one-GPU rehearsals of the
+    multi-rank path - stalls on device tensors on these boxes (seen with a 55 MB bucket and with [T] vectors issued from a side
+    stream), so with gloo device tensors are staged through host memory."""
+    op = torch.distributed.ReduceOp.SUM if op is None else op
+    if t.is_cuda and torch.distributed.get_backend(group) == "gloo":
+        host = t.cpu()
+        torch.distributed.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        torch.distributed.all_reduce(t, op=op, group=group)
+
+
 def _reduce(input_):
     """All-reduce across the model parallel group (mappings.py:29-48), optional fp32 up-cast for bf16."""
     if get_model_parallel_world_size() == 1:
@@ -18,7 +31,7 @@ def _reduce(input_):
     dt = input_.dtype
     if dt == torch.bfloat16 and get_fp32_allreduce():
         input_ = input_.float()
-    torch.distributed.all_reduce(input_, group=get_model_parallel_group())
+    _all_reduce(input_, get_model_parallel_group())
     if dt == torch.bfloat16 and get_fp32_allreduce():
         input_ = input_.bfloat16()
     return input_

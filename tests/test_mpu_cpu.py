@@ -164,3 +164,55 @@ def test_cpu_workload_a_trains():
     assert abs(losses[0] - WA.expected_initial_loss(cfg)) < 0.4   # ln(V) + init noise (the reference logs 11.03 vs ln(50304) = 10.83)
     assert losses[-1] < losses[0] - 0.05 and len(times) == 12
     assert WA.flops_per_step(WA.CONFIG_19M) > 2.5e12   # ~2.8 TFLOP per full-shape step
+
+
+def _worker_overlap(rank, world, port):
+    """Sub-batch interleaving (mpu/overlap.py) over two gloo ranks on CPU: the stages are tensor-parallel MLP blocks built from
+    the mpu mappings (copy -> column shard -> gelu -> row shard -> all-reduce -> residual).  Rows are independent, so the
+    interleaved schedule must reproduce the serial one BIT FOR BIT in the activations and the input gradient; the weight
+    gradients are sums over rows taken in a different order (two partial products added), so they agree to round-off."""
+    _init(rank, world, port)
+    from multimodal_amd import mpu
+    mpu.initialize_model_parallel(2)
+    torch.manual_seed(5)
+    s, b, h, L = 6, 4, 16, 3
+    w1 = [torch.randn(2 * h, h) for _ in range(L)]   # full weights, same on both ranks; each rank keeps its shard
+    w2 = [torch.randn(h, 2 * h) for _ in range(L)]
+    x0 = torch.randn(s, b, h)
+    dy = torch.randn(s, b, h)
+
+    def run(chunks):
+        a = [w[rank * h:(rank + 1) * h].clone().requires_grad_(True) for w in w1]        # column shard [h, h]
+        c = [w[:, rank * h:(rank + 1) * h].clone().requires_grad_(True) for w in w2]     # row shard [h, h]
+        x = x0.clone().requires_grad_(True)
+
+        def stage(i):
+            def f(t):
+                u = torch.nn.functional.gelu(torch.nn.functional.linear(mpu.copy_to_model_parallel_region(t), a[i]))
+                return t + mpu.reduce_from_model_parallel_region(torch.nn.functional.linear(u, c[i]))
+            return f
+        stages = [stage(i) for i in range(L)]
+        if chunks == 1:
+            y = x
+            for st in stages:
+                y = st(y)
+        else:
+            y = torch.cat(mpu.run_interleaved(stages, mpu.split_batch(x, chunks, dim=1)), dim=1)
+        y.backward(dy)
+        return y.detach(), x.grad, [t.grad for t in a + c]
+
+    y1, dx1, g1 = run(1)
+    y2, dx2, g2 = run(2)
+    y4, dx4, g4 = run(4)
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2) and torch.equal(y1, y4) and torch.equal(dx1, dx4)
+    for u, v in zip(g1, g2):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError):
+        mpu.split_batch(x0, 3, dim=1)
+    mpu.destroy_model_parallel()
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_tp_overlap_interleaved_subbatches_equal_serial_world2():
+    mp.spawn(_worker_overlap, args=(2, _free_port()), nprocs=2, join=True)
