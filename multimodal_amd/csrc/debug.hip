@@ -30,11 +30,15 @@ extern "C" int mm_debug_probe_tr_read(void* out, const void* in, const int* row0
 namespace mm {
 int gemm256_debug(void* C, void* aux, const void* A, const void* B, const void* bias, int M, int N, int K, int gelu, int dbg,
                   hipStream_t st);
+int gemm_pp_debug(void* C, void* aux, const void* A, const void* B, const void* bias, int M, int N, int K, int gelu, int dbg,
+                  hipStream_t st);
 }
 extern "C" int mm_debug_gemm256(void* C, void* aux, const void* A, const void* B, const void* bias, int M, int N, int K, int gelu,
                                 int dbg, void* stream) {
     MM_CHECK_ARG(C && A && B && (!gelu || (aux && bias)), "mm_debug_gemm256: null pointer");
-    const int rc = mm::gemm256_debug(C, aux, A, B, bias, M, N, K, gelu, dbg, (hipStream_t)stream);
+    // dbg 0..15: the pipelined kernel of gemm256.hip; 16 + d: the ping-pong kernel of gemm_pp.hip with decomposition bits d
+    const int rc = dbg >= 16 ? mm::gemm_pp_debug(C, aux, A, B, bias, M, N, K, gelu, dbg - 16, (hipStream_t)stream)
+                             : mm::gemm256_debug(C, aux, A, B, bias, M, N, K, gelu, dbg, (hipStream_t)stream);
     if (rc != MM_OK) mm::set_error("mm_debug_gemm256: unsupported shape / variant (M=%d N=%d K=%d dbg=%d)", M, N, K, dbg);
     return rc;
 }

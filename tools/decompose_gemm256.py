@@ -21,7 +21,8 @@ for M, N, K, gelu in shapes:
     aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     st = torch.cuda.current_stream().cuda_stream
     print("M=%d N=%d K=%d gelu=%d  (%.1f GFLOP)" % (M, N, K, gelu, 2.0 * M * N * K / 1e9))
-    for dbg in (0, 4, 1, 2, 3, 5, 6, 7, 8, 12, 13, 14, 0):
+    names.update({16 + k: "pp: " + v for k, v in names.items() if k < 8})
+    for dbg in (0, 4, 5, 6, 7, 16, 20, 17, 18, 21, 22, 23, 16, 0):
         def run(i):
             _lib.check(lib.mm_debug_gemm256(c.data_ptr(), aux.data_ptr(), a[i & 1].data_ptr(), b[i & 1].data_ptr(), bias.data_ptr(),
                                             M, N, K, gelu, dbg, st))
