@@ -14,6 +14,10 @@ GF = 1e9
 attn_f = 4.0 * T * S * H  # full s x s convention; the kernels execute the causal half
 # name fragment -> (label, bound, work per launch [flops or bytes], note)
 ROWS = [
+    ("gemm_nt_pp_k<mm::BF16, 2, false, 256", "h->4h GEMM + bias-GeLU (saves pre-activation), ping-pong 256x256", "mfma", 2.0 * T * 4 * H * H, ""),
+    ("gemm_nt_pp_k<mm::BF16, 6, true, 256", "4h->h data-gradient GEMM + GeLU', ping-pong 256x256", "mfma", 2.0 * T * 4 * H * H, ""),
+    ("gemm_nt_pp_k<mm::BF16, 8, false, 256", "QKV GEMM + bias + rotary, ping-pong 256x256", "mfma", 2.0 * T * 3 * H * H, ""),
+    ("gemm_nt_pp_k<mm::BF16, 0, false, 256", "LM head GEMM, ping-pong 256x256", "mfma", 2.0 * T * V * H, ""),
     ("gemm_nt_256_k<mm::BF16, 2, false>", "h->4h GEMM + bias-GeLU (saves pre-activation)", "mfma", 2.0 * T * 4 * H * H, ""),
     ("gemm_nt_256_k<mm::BF16, 6, true>", "4h->h data-gradient GEMM + GeLU'", "mfma", 2.0 * T * 4 * H * H, ""),
     ("gemm_nt_128_k<mm::BF16, 8, false>", "QKV GEMM + bias + rotary", "mfma", 2.0 * T * 3 * H * H, ""),
