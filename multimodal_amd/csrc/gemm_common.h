@@ -128,7 +128,9 @@ __device__ __forceinline__ void epilogue_phase2(const char* wl, int m_base, int 
         if (!INTERIOR && (m >= M || !(full || half))) continue;
         const size_t off = (size_t)m * ldc + n;
         if (GELU) {
-            if (full) *reinterpret_cast<u32x4*>(aux + off) = v;
+            // the saved pre-activation is next read one whole forward pass later: a streaming store keeps it from
+            // displacing the operands in L2
+            if (full) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(aux + off));
             else *reinterpret_cast<u32x2*>(aux + off) = u32x2{v[0], v[1]};
         }
         if (GELU || RES) {
@@ -136,7 +138,9 @@ __device__ __forceinline__ void epilogue_phase2(const char* wl, int m_base, int 
             unpack8<T>(v, f);
             if (RES) {
                 if (full) {
-                    unpack8<T>(*reinterpret_cast<const u32x4*>(Rsd + off), r8);
+                    // a backward epilogue's saved forward tensor is read exactly once: streaming load
+                    unpack8<T>(GBWD ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Rsd + off))
+                                    : *reinterpret_cast<const u32x4*>(Rsd + off), r8);
                 } else {
                     const u32x2 rr = *reinterpret_cast<const u32x2*>(Rsd + off);
                     unpack8<T>(u32x4{rr[0], rr[1], 0u, 0u}, r8);
