@@ -153,7 +153,11 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     from multimodal_amd import harness, mpu
-    if world > 1:
+    # MM_BENCH_FORCE_PG=1: rehearsal of the N > 1 control flow with ONE rank (a one-rank RCCL group: communicator set-up, the
+    # bucketed gradient all-reduce on device tensors after each graph replay, device barriers) - the one multi-rank path a
+    # one-GPU box can run through RCCL itself.  Needs MASTER_ADDR / MASTER_PORT in the environment.
+    multi = world > 1 or os.environ.get("MM_BENCH_FORCE_PG") == "1"
+    if multi:
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -194,7 +198,8 @@ def main():
         return loss
 
     def reduce_and_update():
-        mpu.allreduce_gradients(params, group=dp_group, transport_dtype=None if backend == "nccl" else torch.float32)
+        mpu.allreduce_gradients(params, group=dp_group, transport_dtype=None if backend == "nccl" else torch.float32,
+                                even_if_alone=multi)
         opt.step()  # clip + Adam: two launches (csrc/optimizer.hip)
 
     def step(i):  # eager launches
@@ -204,7 +209,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if multi:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -230,7 +235,7 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 graph_loss = fwd_bwd()
-                if world == 1:
+                if not multi:
                     opt.step()
             fence()  # (capture launches nothing: the gradients hold no values until the first replay)
         except Exception as e:  # fall back to eager launches and say so in the JSON line
@@ -240,7 +245,7 @@ def main():
     def graph_step(i):
         load_batch(i)
         graph.replay()
-        if world > 1:
+        if multi:
             reduce_and_update()
         return graph_loss
 
@@ -251,7 +256,7 @@ def main():
             loss = fn(a.warmup + i)
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             dt = float(tt.item())
@@ -312,7 +317,7 @@ def main():
             "loss_first_last": [round(losses[0], 4) if losses else None, round(losses[-1], 4)],
             "launch": ("hipGraph replay of the captured step (forward + backward%s), %d timed steps; the same %d steps with eager "
                        "launches on one stream: %.3f ms/step (the roofline kernel's HIP events are recorded in those)"
-                       % (" + clip + Adam" if world == 1 else "; all-reduce + clip + Adam follow eagerly", a.steps, a.steps,
+                       % (" + clip + Adam" if not multi else "; all-reduce + clip + Adam follow eagerly", a.steps, a.steps,
                           dt_eager / a.steps * 1e3)) if dt_graph is not None else
                       ("eager launches" + ((" (%s)" if a.tp > 1 else " (graph capture failed: %s)") % graph_err if graph_err else "")),
             "eager_ms_per_step": round(dt_eager / a.steps * 1e3, 3),
@@ -323,7 +328,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

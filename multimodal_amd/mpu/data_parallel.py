@@ -8,14 +8,14 @@ buckets of `bucket_bytes` and averaged with one all-reduce per bucket.
 import torch
 
 
-def allreduce_gradients(params, group=None, bucket_bytes=256 << 20, average=True, transport_dtype=None):
+def allreduce_gradients(params, group=None, bucket_bytes=256 << 20, average=True, transport_dtype=None, even_if_alone=False):
     """In-place average (or sum) of .grad over the data-parallel group.  No-op for a single-process group.
     transport_dtype (e.g. torch.float32) up-casts the flat bucket for the wire: the fp32_allreduce option of the reference's
     mappings (megatron/mpu/mappings.py:36-46), and what a gloo rehearsal of the multi-rank path needs for 16-bit grads."""
     if group == "single-process" or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
         return 0
     world = torch.distributed.get_world_size(group=group)
-    if world == 1:
+    if world == 1 and not even_if_alone:  # even_if_alone: a one-rank rehearsal that still wants the collective calls made
         return 0
     grads = [p.grad for p in params if p.grad is not None]
     n_calls = 0
