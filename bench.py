@@ -233,7 +233,7 @@ def main():
         try:
             load_batch(0)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):  # the warm-up's stream: autograd's AccumulateGrad nodes were created on it
                 graph_loss = fwd_bwd()
                 if not multi:
                     opt.step()
@@ -271,7 +271,8 @@ def main():
         losses.append(float(loss.detach()))
     dt_plain = None
     if dt_graph is None:  # no graph: the reported value is an eager region with the layer's two streams as configured
-        dt_plain, loss = timed(step)
+        with torch.cuda.stream(side):  # the stream the warm-up ran on (autograd replays each node on its forward stream)
+            dt_plain, loss = timed(step)
     # eager launches of the same K steps, with HIP events around the roofline kernel on its launch stream.  The layer keeps
     # to ONE stream here: on two, the attention kernels of the other stream share the CUs with the probed GEMM and the
     # events would time that mix, not the kernel.
@@ -280,7 +281,8 @@ def main():
         ops.GEMM_EVENT_PROBE = probe
     streams_env = os.environ.get("MM_BRANCH_STREAMS")
     os.environ["MM_BRANCH_STREAMS"] = "0"
-    dt_eager, loss = timed(step)
+    with torch.cuda.stream(side):
+        dt_eager, loss = timed(step)
     if streams_env is None:
         del os.environ["MM_BRANCH_STREAMS"]
     else:
