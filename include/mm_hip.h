@@ -239,6 +239,23 @@ int mm_attn_bwd_rotary(void* dqkv, float* delta, const void* dctx, const void* c
                        float softmax_scale, const void* cos, const void* sin, int rot_d, int rot_offset, int dtype,
                        void* stream);
 
+/* Attention dropout (megatron/model/transformer.py:301-302, 383-384: torch.nn.Dropout(attention_dropout) on the softmax output
+ * inside mpu.get_cuda_rng_tracker().fork()): mm_attn_fwd / mm_attn_bwd_rotary with the probabilities dropped with probability p
+ * and the kept ones scaled by 1 / (1 - p) between the softmax and the P.V product.  The keep mask is never stored: the forward
+ * and both backward kernels regenerate it from rng_state (device uint64[2] {seed, base offset}, as mm_bias_dropout_add_devrng:
+ * a replayed HIP graph draws fresh masks), the launch's position `pos` inside the step and the element's coordinates
+ * (batch * np + head, q, key) - the definition is in csrc/attention.hip and mm_attn_dropout_mask writes that mask as bytes
+ * keep[b, np, s, s] (1 = kept).  p is quantised to 1/65536.  The backward call must repeat the forward's p, rng_state contents
+ * and pos.  The reference draws its mask from the device generator: the two random streams cannot match element for element. */
+int mm_attn_fwd_dropout(void* ctx, float* lse, const void* qkv, const uint8_t* mask, int mask_mode, int mask_batches, int s, int b,
+                        int np, int hn, float softmax_scale, float p, const void* rng_state, unsigned long long pos, int dtype,
+                        void* stream);
+int mm_attn_bwd_dropout(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
+                        const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn, float softmax_scale,
+                        const void* cos, const void* sin, int rot_d, int rot_offset, float p, const void* rng_state,
+                        unsigned long long pos, int dtype, void* stream);
+int mm_attn_dropout_mask(uint8_t* keep, int s, int b, int np, float p, const void* rng_state, unsigned long long pos, void* stream);
+
 /* ------------------------------------------------------------------ cross entropy (TP = 1)
  * Replaces vocab_parallel_cross_entropy(output.float(), labels) (megatron/mpu/cross_entropy.py:27-112 as called from
  * megatron/model/gpt2_model.py:52-70) for one tensor-parallel rank: loss[t] = logsumexp(logits[t, :]) - logits[t, label[t]],

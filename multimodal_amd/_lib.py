@@ -59,6 +59,10 @@ PROTOTYPES = {
     "mm_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mm_attn_bwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
     "mm_attn_bwd_rotary": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mm_attn_fwd_dropout": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_float, c_void_p, ctypes.c_ulonglong, c_int, c_void_p]),
+    "mm_attn_bwd_dropout": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
+                                    ctypes.c_ulonglong, c_int, c_void_p]),
+    "mm_attn_dropout_mask": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, ctypes.c_ulonglong, c_void_p]),
     "mm_cross_entropy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_cross_entropy_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_cross_entropy_fwd_grad": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p]),

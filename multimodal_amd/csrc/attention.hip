@@ -75,14 +75,62 @@ __device__ __forceinline__ float half_sum(float x) {
     return lo + hi;
 }
 
+// ---- attention dropout (reference megatron/model/transformer.py:301-302, 383-384: nn.Dropout on the softmax output under the
+// model-parallel rng tracker's fork).  The keep decision of probability element (batch*head, q, key) is a pure function of the
+// tracker's device-resident Philox-style state {seed, base offset}, the launch's position `pos` inside the step and the element's
+// coordinates, so the forward and both backward kernels regenerate the same mask and nothing of size s x s is stored:
+//     key32 = mix64(seed, offset + pos, batch * np + head)                       (per workgroup)
+//     h     = hash32((q * ceil(s / 2) + (key >> 1)) ^ key32)                      (one 32-bit hash per key PAIR)
+//     keep  = ((key & 1) ? h >> 16 : h & 0xffff) >= thr,  thr = round(p * 65536)  (p is quantised to 1/65536)
+// and kept probabilities are scaled by 1 / (1 - thr / 65536).  mm_attn_dropout_mask writes the same mask as bytes (the tests'
+// oracle applies it explicitly).  The reference draws its mask from the device generator; the two streams cannot match
+// element for element (parity: distributional - mean, independence across heads / calls - and exact against this definition).
+struct DropArgs {
+    const unsigned long long* st;  // {seed, base offset} on the device (mpu/random.py draw_device)
+    unsigned long long pos;        // this launch's position inside the step
+    uint32_t thr;                  // drop when the 16 random bits are below thr
+    float rscale;                  // 1 / (1 - thr / 65536)
+};
+__device__ __forceinline__ uint32_t drop_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t drop_key(const DropArgs& da, uint32_t bh) {
+    unsigned long long z = da.st[0] + 0x9E3779B97F4A7C15ull * (da.st[1] + da.pos + 1ull);
+    z ^= (unsigned long long)(bh + 1u) * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z ^ (z >> 32));
+}
+// the 32 random bits of key pair (key >> 1) of query row q; qh = q * ceil(s / 2)
+__device__ __forceinline__ uint32_t drop_bits(uint32_t key32, uint32_t qh, int key) { return drop_hash((qh + ((uint32_t)key >> 1)) ^ key32); }
+__device__ __forceinline__ bool drop_keep(uint32_t key32, uint32_t qh, int key, uint32_t thr) {
+    const uint32_t h = drop_bits(key32, qh, key);
+    return ((key & 1) ? (h >> 16) : (h & 0xffffu)) >= thr;
+}
+// zero the dropped ones of 16 accumulator registers whose rows are KEYS kb0 + acc_row(i, hh) of one query (forward / dQ layout:
+// registers 4g .. 4g+3 are four consecutive keys = two key pairs = two hashes)
+__device__ __forceinline__ void drop_apply_keys(f32x16& v, uint32_t key32, uint32_t qh, int kb0, int hh, uint32_t thr) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int kb = kb0 + acc_row(4 * g, hh);
+        const uint32_t h0 = drop_bits(key32, qh, kb), h1 = drop_bits(key32, qh, kb + 2);
+        if ((h0 & 0xffffu) < thr) v[4 * g] = 0.f;
+        if ((h0 >> 16) < thr) v[4 * g + 1] = 0.f;
+        if ((h1 & 0xffffu) < thr) v[4 * g + 2] = 0.f;
+        if ((h1 >> 16) < thr) v[4 * g + 3] = 0.f;
+    }
+}
+
 // mask byte for (q, key); mask row base already selected
 __device__ __forceinline__ bool mask_at(const uint8_t* __restrict__ mrow, int key) { return mrow[key] == 1; }
 
 // =====================================================================================  forward
-template <typename T, int HD, int MODE>
+template <typename T, int HD, int MODE, bool DROP = false>
 __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __restrict__ ctx, float* __restrict__ lse, const u16* __restrict__ qkv,
                                                   const uint8_t* __restrict__ mask, int mask_batches, int s, int b, int np,
-                                                  float scale_log2e) {
+                                                  float scale_log2e, DropArgs da = DropArgs{}) {
     typedef Tile<HD> TL;
     typedef typename M32<T>::frag frag;
     constexpr int NDS = HD / 16, NDB = HD / 32;
@@ -100,6 +148,11 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
     frag qf[NDS];
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) qf[ds] = *reinterpret_cast<const frag*>(qbase + (size_t)qrow_c * tok + 16 * ds + 8 * hh);
+    uint32_t dkey = 0, dqh = 0;
+    if constexpr (DROP) {
+        dkey = drop_key(da, (uint32_t)blockIdx.x);  // blockIdx.x = batch * np + head
+        dqh = (uint32_t)qrow_c * (uint32_t)((s + 1) >> 1);
+    }
 
     const int blk_last = min(q0 + 127, s - 1);
     const int ntiles = (MODE == 0) ? (blk_last / 64 + 1) : ((s + 63) / 64);
@@ -194,6 +247,10 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
             }
             l_run += lsum;
             m_run = m_new;
+            if constexpr (DROP) {  // the row sum above is over ALL keys (softmax first, then dropout); P.V only sees the kept ones
+#pragma unroll
+                for (int t = 0; t < 2; ++t) drop_apply_keys(sacc[t], dkey, dqh, kv0 + 32 * t, hh, da.thr);
+            }
             mfma_prio(1);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -215,7 +272,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
     }
 
     const float l_tot = half_sum(l_run);
-    const float inv = 1.0f / l_tot;
+    const float inv = (DROP ? da.rscale : 1.0f) / l_tot;
     if (qrow < s) {
         u16* orow = ctx + ((size_t)qrow * b + bi) * ((size_t)np * HD) + (size_t)hi * HD;
 #pragma unroll
@@ -287,14 +344,14 @@ __device__ __forceinline__ void store_grad_row_rt(u16* __restrict__ dst, const f
 }
 
 // =====================================================================================  backward: dQ
-template <typename T, int HD, int MODE>
+template <typename T, int HD, int MODE, bool DROP = false>
 __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
                                                      const u16* __restrict__ ctx, const float* __restrict__ lse,
                                                      float* __restrict__ delta, const u16* __restrict__ qkv,
                                                      const uint8_t* __restrict__ mask,
                                                      int mask_batches, int s, int b, int np, float scale_log2e, float scale,
                                                      const u16* __restrict__ cos_t, const u16* __restrict__ sin_t, int rot_d,
-                                                     int rot_off) {
+                                                     int rot_off, DropArgs da = DropArgs{}) {
     typedef Tile<HD> TL;
     typedef typename M32<T>::frag frag;
     constexpr int NDS = HD / 16, NDB = HD / 32;
@@ -315,6 +372,11 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
     for (int ds = 0; ds < NDS; ++ds) {
         qf[ds] = *reinterpret_cast<const frag*>(qbase + (size_t)qrow_c * tok + 16 * ds + 8 * hh);
         dof[ds] = *reinterpret_cast<const frag*>(dorow + 16 * ds + 8 * hh);
+    }
+    uint32_t dkey = 0, dqh = 0;
+    if constexpr (DROP) {
+        dkey = drop_key(da, (uint32_t)blockIdx.x);
+        dqh = (uint32_t)qrow_c * (uint32_t)((s + 1) >> 1);
     }
     const float lse2_ld = lse[((size_t)bi * np + hi) * s + qrow_c] * kLog2e;
     // delta[q] = sum_d dO[q][d] * O[q][d]: this wave holds its 32 rows of dO as MFMA fragments (half the dims per lane half), so
@@ -385,6 +447,11 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
                     dpacc = M32<T>::run(row_frag<T, HD>(vs, 32 * t, ds, lane), dof[ds], dpacc);
                 }
                 mfma_prio(0);
+                if constexpr (DROP) {  // dP = keep / (1 - p) * (dO . V): the gradient through the dropped probabilities
+                    drop_apply_keys(dpacc, dkey, dqh, kv0 + 32 * t, hh, da.thr);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dpacc[i] *= da.rscale;
+                }
                 if (MODE == 1) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -442,13 +509,13 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
 }
 
 // =====================================================================================  backward: dK, dV
-template <typename T, int HD, int MODE>
+template <typename T, int HD, int MODE, bool DROP = false>
 __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* __restrict__ dqkv, const u16* __restrict__ dctx,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       const u16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                       int mask_batches, int s, int b, int np, float scale_log2e, float scale,
                                                       const u16* __restrict__ cos_t, const u16* __restrict__ sin_t, int rot_d,
-                                                      int rot_off) {
+                                                      int rot_off, DropArgs da = DropArgs{}) {
     typedef Tile<HD> TL;
     typedef typename M32<T>::frag frag;
     constexpr int NDS = HD / 16, NDB = HD / 32;
@@ -469,6 +536,8 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
 
     const int krow = k0 + wave * 32 + r;
     const int krow_c = krow < s ? krow : s - 1;
+    uint32_t dkey = 0;
+    if constexpr (DROP) dkey = drop_key(da, (uint32_t)blockIdx.x);
     frag kf[NDS], vf[NDS];
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) {
@@ -541,6 +610,16 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                 }
                 mfma_prio(0);
                 float pv[16];
+                bool keep[16];
+                if constexpr (DROP) {  // here the lane is a KEY and the registers are queries: one hash per element
+                    const uint32_t half_s = (uint32_t)((s + 1) >> 1);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int q = min(q0t + 32 * t + acc_row(i, hh), s - 1);
+                        keep[i] = drop_keep(dkey, (uint32_t)q * half_s, krow_c, da.thr);
+                        dpacc[i] = keep[i] ? dpacc[i] * da.rscale : 0.f;
+                    }
+                }
                 // wave-uniform: only tiles on this wave's diagonal (or the ragged last tile) pay for the compare/select
                 const bool need_mask = (wave_first + 31 > q0t + 32 * t) || (q0t + 32 * t + 32 > s);
                 if (MODE == 0) {
@@ -594,6 +673,10 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                         }
                     }
                 }
+                if constexpr (DROP) {  // dV sees the dropped, rescaled probabilities; dS above used the undropped ones
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) pv[i] = keep[i] ? pv[i] * da.rscale : 0.f;
+                }
                 mfma_prio(1);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -627,14 +710,19 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
 
 template <typename T, int HD>
 static int launch_fwd(void* ctx, float* lse, const void* qkv, const uint8_t* mask, int mode, int mb, int s, int b, int np,
-                      float scale, hipStream_t st) {
+                      float scale, hipStream_t st, const DropArgs* da = nullptr) {
     // Grid: x = (batch, head) - fastest - and y = 128-row block, heaviest causal blocks first.  Dispatch is x-major, so
     // (1) every heavy block of every head starts before any light one (longest-processing-time order: the causal
     // triangle's 16:1 work spread no longer leaves a tail), and (2) workgroup id % 8 = head % 8 picks the XCD, so all
     // blocks that stream one head's K/V share one XCD's L2 instead of spreading every head over all eight.
     dim3 grid(b * np, (s + 127) / 128), block(256);
     const float sl2 = scale * kLog2e;
-    if (mode == 0)
+    if (da) {  // attention dropout (training with attention_dropout > 0): its own instantiations, the p = 0 kernels stay as they are
+        if (mode == 0)
+            attn_fwd_k<T, HD, 0, true><<<grid, block, 0, st>>>((u16*)ctx, lse, (const u16*)qkv, nullptr, 1, s, b, np, sl2, *da);
+        else
+            attn_fwd_k<T, HD, 1, true><<<grid, block, 0, st>>>((u16*)ctx, lse, (const u16*)qkv, mask, mb, s, b, np, sl2, *da);
+    } else if (mode == 0)
         attn_fwd_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)ctx, lse, (const u16*)qkv, nullptr, 1, s, b, np, sl2);
     else
         attn_fwd_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)ctx, lse, (const u16*)qkv, mask, mb, s, b, np, sl2);
@@ -645,20 +733,52 @@ static int launch_fwd(void* ctx, float* lse, const void* qkv, const uint8_t* mas
 template <typename T, int HD>
 static int launch_bwd(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
                       const uint8_t* mask, int mode, int mb, int s, int b, int np, float scale, const u16* cs, const u16* sn,
-                      int rd, int ro, hipStream_t st) {
+                      int rd, int ro, hipStream_t st, const DropArgs* da = nullptr) {
     dim3 grid(b * np, (s + 127) / 128), block(256);  // head-fast, heavy blocks first (see launch_fwd)
     const float sl2 = scale * kLog2e;
+    const uint8_t* mk = mode == 0 ? nullptr : mask;
+    const int mbb = mode == 0 ? 1 : mb;
     // dQ first: it also leaves delta[b, np, s] for the dK/dV kernel behind it on the stream
-    if (mode == 0) {
-        attn_bwd_dq_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, (const u16*)ctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale, cs, sn, rd, ro);
-        MM_CHECK_LAUNCH();
-        attn_bwd_dkv_k<T, HD, 0><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, nullptr, 1, s, b, np, sl2, scale, cs, sn, rd, ro);
+#define MM_ATTN_BWD(MODE, DROP, ...)                                                                                                \
+    do {                                                                                                                            \
+        attn_bwd_dq_k<T, HD, MODE, DROP><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, (const u16*)ctx, lse, delta,           \
+                                                                 (const u16*)qkv, mk, mbb, s, b, np, sl2, scale, cs, sn, rd, ro __VA_ARGS__); \
+        MM_CHECK_LAUNCH();                                                                                                          \
+        attn_bwd_dkv_k<T, HD, MODE, DROP><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mk, mbb, \
+                                                                  s, b, np, sl2, scale, cs, sn, rd, ro __VA_ARGS__);                 \
+    } while (0)
+    if (da) {
+        if (mode == 0) MM_ATTN_BWD(0, true, , *da);
+        else MM_ATTN_BWD(1, true, , *da);
     } else {
-        attn_bwd_dq_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, (const u16*)ctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale, cs, sn, rd, ro);
-        MM_CHECK_LAUNCH();
-        attn_bwd_dkv_k<T, HD, 1><<<grid, block, 0, st>>>((u16*)dqkv, (const u16*)dctx, lse, delta, (const u16*)qkv, mask, mb, s, b, np, sl2, scale, cs, sn, rd, ro);
+        if (mode == 0) MM_ATTN_BWD(0, false);
+        else MM_ATTN_BWD(1, false);
     }
+#undef MM_ATTN_BWD
     MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
+// the keep mask of the attention dropout as bytes [b, np, s, s] (1 = kept): the definition the kernels above implement
+__global__ __launch_bounds__(256) void attn_dropout_mask_k(uint8_t* __restrict__ keep, int s, DropArgs da) {
+    const uint32_t dkey = drop_key(da, (uint32_t)blockIdx.y);
+    const uint32_t half_s = (uint32_t)((s + 1) >> 1);
+    const size_t n = (size_t)s * s;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i / s), k = (int)(i % s);
+        keep[(size_t)blockIdx.y * n + i] = drop_keep(dkey, (uint32_t)q * half_s, k, da.thr) ? 1 : 0;
+    }
+}
+
+static int make_drop(const char* fn, DropArgs& da, float p, const void* rng_state, unsigned long long pos) {
+    MM_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout probability %g outside [0, 1)", fn, (double)p);
+    MM_CHECK_ARG(rng_state != nullptr, "%s: rng_state (device uint64[2] {seed, offset}) missing", fn);
+    long thr = lrintf(p * 65536.0f);
+    thr = thr < 0 ? 0 : (thr > 65535 ? 65535 : thr);
+    da.st = (const unsigned long long*)rng_state;
+    da.pos = pos;
+    da.thr = (uint32_t)thr;
+    da.rscale = 65536.0f / (float)(65536 - thr);
     return MM_OK;
 }
 
@@ -691,10 +811,59 @@ extern "C" int mm_attn_fwd(void* ctx, float* lse, const void* qkv, const uint8_t
     });
 }
 
+extern "C" int mm_attn_fwd_dropout(void* ctx, float* lse, const void* qkv, const uint8_t* mask, int mask_mode, int mask_batches,
+                                   int s, int b, int np, int hn, float softmax_scale, float p, const void* rng_state,
+                                   unsigned long long pos, int dtype, void* stream) {
+    MM_CHECK_ARG(ctx && lse && qkv, "mm_attn_fwd_dropout: null pointer");
+    if (int rc = check_common("mm_attn_fwd_dropout", mask_mode, mask, mask_batches, s, b, np, hn)) return rc;
+    MM_CHECK_ARG(aligned16(qkv) && aligned16(ctx), "mm_attn_fwd_dropout: qkv/ctx must be 16-byte aligned");
+    DropArgs da;
+    if (int rc = make_drop("mm_attn_fwd_dropout", da, p, rng_state, pos)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        if (hn == 64) return launch_fwd<T, 64>(ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale, st, &da);
+        return launch_fwd<T, 128>(ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale, st, &da);
+    });
+}
+
+static int attn_bwd_impl(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
+                         const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn, float softmax_scale,
+                         const void* cos, const void* sin, int rot_d, int rot_offset, int dtype, void* stream, const DropArgs* da);
+
+extern "C" int mm_attn_bwd_dropout(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
+                                   const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn,
+                                   float softmax_scale, const void* cos, const void* sin, int rot_d, int rot_offset, float p,
+                                   const void* rng_state, unsigned long long pos, int dtype, void* stream) {
+    DropArgs da;
+    if (int rc = make_drop("mm_attn_bwd_dropout", da, p, rng_state, pos)) return rc;
+    return attn_bwd_impl(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, hn, softmax_scale, cos, sin, rot_d,
+                         rot_offset, dtype, stream, &da);
+}
+
+extern "C" int mm_attn_dropout_mask(uint8_t* keep, int s, int b, int np, float p, const void* rng_state, unsigned long long pos,
+                                    void* stream) {
+    MM_CHECK_ARG(keep && s > 0 && b > 0 && np > 0 && (long)b * np <= 65535, "mm_attn_dropout_mask: bad arguments");
+    DropArgs da;
+    if (int rc = make_drop("mm_attn_dropout_mask", da, p, rng_state, pos)) return rc;
+    const size_t n = (size_t)s * s;
+    dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 1024), b * np);
+    attn_dropout_mask_k<<<grid, 256, 0, (hipStream_t)stream>>>(keep, s, da);
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
 extern "C" int mm_attn_bwd_rotary(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
                                   const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn,
                                   float softmax_scale, const void* cos, const void* sin, int rot_d, int rot_offset, int dtype,
                                   void* stream) {
+    return attn_bwd_impl(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, hn, softmax_scale, cos, sin, rot_d,
+                         rot_offset, dtype, stream, nullptr);
+}
+
+static int attn_bwd_impl(void* dqkv, float* delta, const void* dctx, const void* ctx, const float* lse, const void* qkv,
+                         const uint8_t* mask, int mask_mode, int mask_batches, int s, int b, int np, int hn, float softmax_scale,
+                         const void* cos, const void* sin, int rot_d, int rot_offset, int dtype, void* stream, const DropArgs* da) {
     MM_CHECK_ARG(dqkv && delta && dctx && ctx && lse && qkv, "mm_attn_bwd: null pointer");
     if (int rc = check_common("mm_attn_bwd", mask_mode, mask, mask_batches, s, b, np, hn)) return rc;
     MM_CHECK_ARG(aligned16(qkv) && aligned16(ctx) && aligned16(dctx) && aligned16(dqkv), "mm_attn_bwd: tensors must be 16-byte aligned");
@@ -708,9 +877,9 @@ extern "C" int mm_attn_bwd_rotary(void* dqkv, float* delta, const void* dctx, co
         using T = decltype(t);
         if (hn == 64)
             return launch_bwd<T, 64>(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale,
-                                     (const u16*)cos, (const u16*)sin, rot_d, rot_offset, st);
+                                     (const u16*)cos, (const u16*)sin, rot_d, rot_offset, st, da);
         return launch_bwd<T, 128>(dqkv, delta, dctx, ctx, lse, qkv, mask, mask_mode, mask_batches, s, b, np, softmax_scale,
-                                  (const u16*)cos, (const u16*)sin, rot_d, rot_offset, st);
+                                  (const u16*)cos, (const u16*)sin, rot_d, rot_offset, st, da);
     });
 }
 

@@ -282,14 +282,15 @@ class AttentionCoreFn(torch.autograd.Function):
     The rotary is applied in place on `mixed` (the QKV GEMM's output, not needed again)."""
 
     @staticmethod
-    def forward(ctx, mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale):
+    def forward(ctx, mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale, dropout=None):
         s, b = mixed.size(0), mixed.size(1)
         qkv = mixed.view(s, b, np_, 3 * hn)
         if rotary_ndims > 0:
             ops.rotary_qk_inplace(qkv, cos, sin, s, b, np_, hn, rotary_ndims)
-        out, lse = ops.attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask)
+        out, lse = ops.attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask, dropout=dropout)
         ctx.save_for_backward(qkv, out, lse, cos, sin, mask)
         ctx.dims = (s, b, np_, hn, rotary_ndims, softmax_scale)
+        ctx.dropout = dropout  # (p, rng_state, pos): the backward regenerates the forward's mask from it
         return out
 
     @staticmethod
@@ -297,12 +298,14 @@ class AttentionCoreFn(torch.autograd.Function):
         qkv, out, lse, cos, sin, mask = ctx.saved_tensors
         s, b, np_, hn, d, scale = ctx.dims
         # the rotary backward rides in the dq / dk stores of the attention backward kernels
-        dqkv = ops.attn_bwd(dctx, out, lse, qkv, s, b, np_, hn, scale, mask, rotary=(cos, sin, d, 0) if d > 0 else None)
-        return dqkv.view(s, b, np_ * 3 * hn), None, None, None, None, None, None, None
+        dqkv = ops.attn_bwd(dctx, out, lse, qkv, s, b, np_, hn, scale, mask, rotary=(cos, sin, d, 0) if d > 0 else None,
+                            dropout=ctx.dropout)
+        return dqkv.view(s, b, np_ * 3 * hn), None, None, None, None, None, None, None, None
 
 
-def attention_core(mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale):
-    return AttentionCoreFn.apply(mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale)
+def attention_core(mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale, dropout=None):
+    """dropout = (p, rng_state, pos) or None: attention dropout on the softmax output (ops.attn_fwd)."""
+    return AttentionCoreFn.apply(mixed, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale, dropout)
 
 
 def bias_needed(ctx):
@@ -316,7 +319,7 @@ class QkvAttentionFn(torch.autograd.Function):
     Falls back to GEMM + in-place rotary for shapes the fused epilogue does not take (head size 128)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale):
+    def forward(ctx, x, weight, bias, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale, dropout=None):
         s, b = x.size(0), x.size(1)
         d = rotary_ndims
         if d > 0 and bias is not None and ops.qkv_rotary_supported(hn, d, weight.size(0), weight.size(1), s * b, b):
@@ -326,27 +329,29 @@ class QkvAttentionFn(torch.autograd.Function):
             if d > 0:
                 ops.rotary_qk_inplace(mixed.view(s, b, np_, 3 * hn), cos, sin, s, b, np_, hn, d)
         qkv = mixed.view(s, b, np_, 3 * hn)
-        out, lse = ops.attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask)
+        out, lse = ops.attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask, dropout=dropout)
         ctx.save_for_backward(x, weight, qkv, out, lse, cos, sin, mask)
         ctx.dims = (s, b, np_, hn, d, softmax_scale)
         ctx.has_bias = bias is not None
+        ctx.dropout = dropout
         return out
 
     @staticmethod
     def backward(ctx, dctx):
         x, weight, qkv, out, lse, cos, sin, mask = ctx.saved_tensors
         s, b, np_, hn, d, scale = ctx.dims
-        dmixed = ops.attn_bwd(dctx, out, lse, qkv, s, b, np_, hn, scale, mask, rotary=(cos, sin, d, 0) if d > 0 else None)
+        dmixed = ops.attn_bwd(dctx, out, lse, qkv, s, b, np_, hn, scale, mask, rotary=(cos, sin, d, 0) if d > 0 else None,
+                              dropout=ctx.dropout)
         d2 = dmixed.view(s * b, np_ * 3 * hn)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(d2, weight_t(weight)).view(x.shape)
         dw, db = _wgrad_bias(d2, _flat2d(x), ctx.needs_input_grad[1], bias_needed(ctx))
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def qkv_attention(x, weight, bias, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale):
-    return QkvAttentionFn.apply(x, weight, bias, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale)
+def qkv_attention(x, weight, bias, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale, dropout=None):
+    return QkvAttentionFn.apply(x, weight, bias, cos, sin, mask, np_, hn, rotary_ndims, softmax_scale, dropout)
 
 
 class BiasDropoutAddFn(torch.autograd.Function):

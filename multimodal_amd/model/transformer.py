@@ -113,9 +113,11 @@ class ParallelSelfAttention(nn.Module):
         else:
             self.rotary_emb = None
         self.upper_triang_fusion = bool(neox_args.scaled_upper_triang_masked_softmax_fusion)
-        self.dropout_p = neox_args.attention_dropout
-        if self.dropout_p != 0:
-            raise NotImplementedError("attention_dropout > 0 is not on the fused path yet (every listed config uses 0)")
+        # torch.nn.Dropout(attention_dropout) on the softmax output (transformer.py:301-302, 383-384): inside the attention
+        # kernels, mask regenerated from the model-parallel rng stream in the backward (include/mm_hip.h, mm_attn_fwd_dropout)
+        self.dropout_p = float(neox_args.attention_dropout)
+        if not 0.0 <= self.dropout_p < 1.0:
+            raise ValueError("attention_dropout must be in [0, 1)")
         self.dense = mpu.RowParallelLinear(
             neox_args=neox_args, input_size=neox_args.hidden_size, output_size=neox_args.hidden_size,
             input_is_parallel=True, init_method=output_layer_init_method, skip_bias_add=True,
@@ -138,8 +140,13 @@ class ParallelSelfAttention(nn.Module):
         # node: the fused QKV activation [s, b, np*3*hn] (per-head interleaved q, k, v) is produced already rotated
         qkv_lin = self.query_key_value
         x = mpu.copy_to_model_parallel_region(hidden_states)
+        dropout = None
+        if self.dropout_p > 0.0 and self.training:
+            with mpu.get_cuda_rng_tracker().fork():  # the reference's fork: a different stream per TP rank (its heads differ)
+                state, pos = mpu.get_cuda_rng_tracker().draw_device(hidden_states.device)
+            dropout = (self.dropout_p, state, pos)
         context = Fn.qkv_attention(x, qkv_lin.weight, qkv_lin.bias, cos, sin, mask, np_, hn, d,
-                                   1.0 / self.norm_factor)  # [s, b, np*hn]
+                                   1.0 / self.norm_factor, dropout)  # [s, b, np*hn]
         return self.dense(context)
 
 

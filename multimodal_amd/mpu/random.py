@@ -67,8 +67,7 @@ class RngStatesTracker:
         if st is None:
             seed, off = self.states_[self.active_]
             st = self.dev_[key] = torch.tensor([seed, off], dtype=torch.int64, device=device)
-            self.pending_[key] = 0
-        pos = self.pending_[key]
+        pos = self.pending_.get(key, 0)  # (absent after set_states() of a snapshot taken before the stream's first draw)
         self.pending_[key] = pos + n
         return st, pos
 

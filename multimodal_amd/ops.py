@@ -415,21 +415,46 @@ def adapter_bwd_dx(dy, w2, w1, h1):
 
 
 # ---------------------------------------------------------------------------- attention
-def attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask=None):
+def _dropout_args(dropout):
+    """dropout = (p, rng_state, pos): rng_state the tracker's device int64[2] {seed, base offset} (mpu/random.py draw_device),
+    pos the launch's position inside the step."""
+    p, state, pos = dropout
+    _need_cuda(state)
+    if state.dtype != torch.int64 or state.numel() != 2:
+        raise RuntimeError("attention dropout: rng_state must be a device int64[2] {seed, offset}")
+    return float(p), state, int(pos)
+
+
+def attn_dropout_mask(s, b, np_, dropout):
+    """The keep mask [b, np, s, s] (uint8, 1 = kept) that attn_fwd / attn_bwd apply for `dropout` = (p, rng_state, pos)."""
+    p, state, pos = _dropout_args(dropout)
+    keep = torch.empty(b, np_, s, s, dtype=torch.uint8, device=state.device)
+    check(get_lib().mm_attn_dropout_mask(keep.data_ptr(), s, b, np_, p, state.data_ptr(), pos, _stream()), "attn_dropout_mask")
+    return keep
+
+
+def attn_fwd(qkv, s, b, np_, hn, softmax_scale, mask=None, dropout=None):
     """qkv: contiguous [s, b, np, 3*hn] (post-rotary).  mask None => implicit causal; otherwise a
-    uint8/bool [1|b, 1, s, s] tensor (1 = masked, filled with -10000).  Returns (ctx [s, b, np*hn], lse [b, np, s])."""
+    uint8/bool [1|b, 1, s, s] tensor (1 = masked, filled with -10000).  dropout = (p, rng_state, pos): attention dropout
+    (see _dropout_args).  Returns (ctx [s, b, np*hn], lse [b, np, s])."""
     _need_cuda(qkv, mask)
     if not qkv.is_contiguous() or qkv.numel() != s * b * np_ * 3 * hn:
         raise RuntimeError("attn_fwd: qkv must be contiguous [s, b, np, 3*hn]")
     ctx = torch.empty(s, b, np_ * hn, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(b, np_, s, dtype=torch.float32, device=qkv.device)
     m, mode, mb = _mask_args(mask, s, b)
+    if dropout is not None:
+        p, state, pos = _dropout_args(dropout)
+        check(get_lib().mm_attn_fwd_dropout(ctx.data_ptr(), lse.data_ptr(), qkv.data_ptr(), _ptr(m), mode, mb, s, b, np_, hn,
+                                            float(softmax_scale), p, state.data_ptr(), pos, dtype_code(qkv.dtype), _stream()),
+              "attn_fwd_dropout")
+        return ctx, lse
     check(get_lib().mm_attn_fwd(ctx.data_ptr(), lse.data_ptr(), qkv.data_ptr(), _ptr(m), mode, mb, s, b, np_, hn,
                                 float(softmax_scale), dtype_code(qkv.dtype), _stream()), "attn_fwd")
     return ctx, lse
 
 
-def attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, softmax_scale, mask=None, rotary=None):
+def attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, softmax_scale, mask=None, rotary=None, dropout=None):
     """Gradient wrt qkv [s, b, np, 3*hn].  rotary = (cos, sin, d, offset): also apply the rotary embedding's backward to
     the q / k gradients inside the kernels' stores (the result is then the gradient wrt the PRE-rotary activation)."""
     _need_cuda(dctx, ctx, lse, qkv, mask)
@@ -445,6 +470,13 @@ def attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, softmax_scale, mask=None, rotar
         if cos.dtype != qkv.dtype or sin.dtype != qkv.dtype or cos.size(-1) != d or cos.numel() < (off + s) * d:
             raise RuntimeError("attn_bwd: cos/sin tables must be [>=offset+s, d] in the activation dtype")
         cos, sin = cos.contiguous(), sin.contiguous()
+    if dropout is not None:  # the forward's (p, rng_state, pos): the kernels regenerate its mask
+        p, state, pos = _dropout_args(dropout)
+        check(get_lib().mm_attn_bwd_dropout(dqkv.data_ptr(), delta.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                            qkv.data_ptr(), _ptr(m), mode, mb, s, b, np_, hn, float(softmax_scale), _ptr(cos),
+                                            _ptr(sin), d, off, p, state.data_ptr(), pos, dtype_code(qkv.dtype), _stream()),
+              "attn_bwd_dropout")
+        return dqkv
     check(get_lib().mm_attn_bwd_rotary(dqkv.data_ptr(), delta.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
                                        qkv.data_ptr(), _ptr(m), mode, mb, s, b, np_, hn, float(softmax_scale), _ptr(cos),
                                        _ptr(sin), d, off, dtype_code(qkv.dtype), _stream()), "attn_bwd")
