@@ -39,14 +39,15 @@ def initialize_model_parallel(model_parallel_size, topology=None, fp32_allreduce
     assert _DATA_PARALLEL_GROUP is None, "data parallel group is already initialized"
     assert _MODEL_PARALLEL_GROUP is None, "model parallel group is already initialized"
     assert _FP32_ALLREDUCE is None, "fp32_allreduce is already initialized"
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
+    have_pg = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if have_pg:
         world_size, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
     else:
         world_size, rank = 1, 0
     if world_size < model_parallel_size:
         raise ValueError("world size cannot be smaller than model parallel size")
     tp_lists, dp_lists = group_layout(world_size, model_parallel_size)
-    if world_size == 1:
+    if world_size == 1 and not have_pg:  # (a one-rank process group gets real one-rank groups below)
         _MODEL_PARALLEL_GROUP = _DATA_PARALLEL_GROUP = "single-process"
         _MODEL_PARALLEL_RANKS = _DATA_PARALLEL_RANKS = [0]
     else:
