@@ -444,6 +444,7 @@ static int launch_bottleneck(void* Y, void* Hout, const void* X, const void* Wa,
     }
     MM_AD_CASE(1024, 128)
     MM_AD_CASE(512, 64)
+    MM_AD_CASE(512, 128)  // summit-70m-openclipH: h = 512 with the default adapter_downsample_factor 4
 #undef MM_AD_CASE
     return MM_EUNSUPPORTED;
 }
@@ -452,7 +453,7 @@ static int launch_bottleneck(void* Y, void* Hout, const void* X, const void* Wa,
 
 using namespace mm;
 
-extern "C" int mm_adapter_supported(int h, int r) { return (h == 1024 && r == 128) || (h == 512 && r == 64); }
+extern "C" int mm_adapter_supported(int h, int r) { return (h == 1024 && r == 128) || (h == 512 && (r == 64 || r == 128)); }
 
 static int check_adapter(const char* fn, int rows, int h, int r) {
     MM_CHECK_ARG(rows > 0, "%s: rows=%d must be positive", fn, rows);

@@ -29,10 +29,10 @@ CONFIGS = {
                 gpt_j_residual=False, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
                 add_adapters=False, adapter_downsample_factor=8, freeze_lm=False, micro_batch=4,
                 padded_vocab_size=50304, encoder_out_dim=0, prefix_len=0, image_embed_dropout_prob=0.0),
-    # configs/summit-70m-openclipH.yml:16-33
+    # configs/summit-70m-openclipH.yml:16-33 (no adapter_downsample_factor key: the default, 4 - neox_args.py:98)
     "summit-70m-openclipH": dict(hidden_size=512, num_attention_heads=8, num_layers=6, seq_length=2048, rotary_pct=0.25,
                                  gpt_j_residual=True, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
-                                 add_adapters=True, adapter_downsample_factor=8, freeze_lm=True, micro_batch=4,
+                                 add_adapters=True, adapter_downsample_factor=4, freeze_lm=True, micro_batch=4,
                                  padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1),
     # configs/summit-1-3B.yml:5-33 - BASELINE.json configs[3] runs it at tensor-parallel 2 x data-parallel 4 (the YAML's own
     # model-parallel-size 3 / pipe 2 is a Summit layout; 18 heads % 2 == 0 and 2304 % 2 == 0 satisfy transformer.py:210-217).

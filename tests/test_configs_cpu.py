@@ -1,0 +1,35 @@
+"""harness.CONFIGS against the reference's own YAML files (tests/golden/configs.json, written by tests/golden/make_config_fixture.py
+from /root/reference/configs with yaml.safe_load): the workloads bench.py and the tests build are the reference's."""
+import json
+import os
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NAMES = ["19M", "magma_pythia_410M", "summit-70m-openclipH", "summit-1-3B", "6-7B"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_harness_config_matches_reference_yaml(name):
+    from multimodal_amd import harness
+    ref = json.load(open(os.path.join(HERE, "golden", "configs.json")))[name]
+    cfg = harness.CONFIGS[name]
+    for k in ("hidden_size", "num_attention_heads", "num_layers", "seq_length", "gpt_j_residual", "bias_gelu_fusion",
+              "scaled_upper_triang_masked_softmax_fusion", "add_adapters", "freeze_lm"):
+        assert cfg[k] == ref[k], (name, k, cfg[k], ref[k])
+    assert cfg["rotary_pct"] == pytest.approx(ref["rotary_pct"])
+    assert cfg["micro_batch"] == ref["train_micro_batch_size_per_gpu"]
+    assert ref["pos_emb"] == "rotary" and ref["hidden_dropout"] == 0 and ref["attention_dropout"] == 0
+    if cfg["add_adapters"]:
+        assert cfg["adapter_downsample_factor"] == ref["adapter_downsample_factor"]
+    multimodal = ref["encoder_name"] is not None
+    if name == "6-7B":   # BASELINE.json configs[4] runs the 6-7B SHAPE as a multimodal model: the YAML itself is text-only
+        assert not multimodal and cfg["prefix_len"] == 1
+    else:
+        assert (cfg["prefix_len"] > 0) == multimodal
+        if multimodal:
+            assert cfg["image_embed_dropout_prob"] == pytest.approx(ref["image_embed_dropout_prob"])
+    # the divisibility rules of megatron/model/transformer.py:210-217 at the tensor-parallel degree BASELINE.json runs it with
+    tp = {"summit-1-3B": 2, "6-7B": 8}.get(name, 1)
+    assert cfg["hidden_size"] % tp == 0 and cfg["num_attention_heads"] % tp == 0
+    assert cfg["hidden_size"] % cfg["num_attention_heads"] == 0

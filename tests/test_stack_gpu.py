@@ -137,3 +137,38 @@ def test_two_stream_layer_equals_one_stream_layer(cuda_device, monkeypatch):
             assert torch.equal(l0, l1)
             for a, b in zip(g0, g1):
                 assert torch.equal(a, b)
+
+
+def test_summit_70m_recipe_stack_fused_adapters_equal_gemm_chain(cuda_device, monkeypatch):
+    """BASELINE.json configs[2] (configs/summit-70m-openclipH.yml): h = 512, 8 heads, GPT-J residual, erf GeLU, unfused softmax
+    flags, adapters with the DEFAULT downsample factor 4 (r = 128) on a frozen LM - at reduced depth / length / vocabulary.
+    The fused adapter kernels (h = 512, r = 128 instantiation) must reproduce the GEMM-chain adapters bit for bit in a whole
+    training step, and a few optimizer steps must lower the loss."""
+    from multimodal_amd import harness, mpu, ops
+    from multimodal_amd.optim import FusedAdam
+    mpu.destroy_model_parallel()
+    mpu.initialize_model_parallel(1)
+    cfg = dict(harness.CONFIGS["summit-70m-openclipH"])
+    assert cfg["adapter_downsample_factor"] == 4 and ops.adapter_supported(cfg["hidden_size"], cfg["hidden_size"] // 4)
+    cfg.update(num_layers=2, seq_length=256, padded_vocab_size=2048, image_embed_dropout_prob=0.0)
+    mpu.model_parallel_cuda_manual_seed(23)
+    torch.manual_seed(23)
+    model = harness.MagmaStack(cfg, dtype=torch.bfloat16, device=cuda_device)
+    model.train()
+    batch = harness.synthetic_batch(cfg, cuda_device, seed=3)
+    l_fused, g_fused = _loss_and_grads(model, batch, 5)
+    monkeypatch.setattr(ops, "adapter_supported", lambda h, r: False)
+    l_chain, g_chain = _loss_and_grads(model, batch, 5)
+    monkeypatch.undo()
+    assert torch.equal(l_fused, l_chain)
+    for a, b in zip(g_fused, g_chain):
+        assert torch.equal(a, b)
+    opt = FusedAdam(model.trainable_parameters(), lr=2e-3, max_grad_norm=1.0)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        loss = model(*batch)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0] - 0.05, losses
