@@ -24,9 +24,9 @@ ROWS = [
     ("gemm_nt_256_k<mm::BF16, 0, false>", "LM head GEMM", "mfma", 2.0 * T * V * H, ""),
     ("gemm_nt_128_k<mm::BF16, 0, false>", "N = h GEMMs (dense, 4h->h, and the dgrads of QKV / dense / h->4h / head)", "mfma",
      (24 * 2.0 * T * H * (H + 4 * H + 3 * H + H + 4 * H) + 2.0 * T * V * H) / (24 * 5 + 1), "launch-weighted mean of 6 shapes"),
-    ("attn_fwd_k<mm::BF16, 64, 0>", "attention forward", "mfma", attn_f, "full s x s convention (causal-exact is half)"),
-    ("attn_bwd_dkv_k<mm::BF16, 64, 0>", "attention backward dK, dV (+ rotary backward on dK)", "mfma", attn_f * 2.0, "4 of 5 products; convention as above"),
-    ("attn_bwd_dq_k<mm::BF16, 64, 0>", "attention backward dQ (+ rotary backward)", "mfma", attn_f * 1.5, "3 products (S and dP recomputed)"),
+    ("attn_fwd_k<mm::BF16, 64, 0", "attention forward", "mfma", attn_f, "full s x s convention (causal-exact is half)"),
+    ("attn_bwd_dkv_k<mm::BF16, 64, 0", "attention backward dK, dV (+ rotary backward on dK)", "mfma", attn_f * 2.0, "4 of 5 products; convention as above"),
+    ("attn_bwd_dq_k<mm::BF16, 64, 0", "attention backward dQ (+ rotary backward)", "mfma", attn_f * 1.5, "3 products (S and dP recomputed)"),
     ("bottleneck_k<mm::BF16, 1024, 128, 0>", "adapter forward", "hbm", 2.0 * (2 * T * H + T * R), "o in, out + h1 out"),
     ("bottleneck_k<mm::BF16, 1024, 128, 1>", "adapter data gradient", "hbm", 2.0 * (2 * T * H + 2 * T * R), "dy + h1 in, dx + dpre out"),
     ("bottleneck_dma_k<mm::BF16, 1024, 128, 0, false>", "adapter forward", "hbm", 2.0 * (2 * T * H + T * R), "o in, out + h1 out"),
