@@ -1,4 +1,5 @@
-// optimizer.hip - mixed-precision Adam with global-norm gradient clipping over a LIST of tensors, two launches per step.
+// optimizer.hip - mixed-precision Adam with global-norm gradient clipping over a LIST of tensors, two launches per step
+// (three above 16 k chunks = 33 M parameters: see adam_norm_reduce_k).
 //
 // Reference: the optimizer the recipe builds at megatron/training.py:571-580 (apex / DeepSpeed FusedAdam, adam_w_mode,
 // betas (0.9, 0.95), eps 1e-8: configs/magma_setup.yml:38-45) under DeepSpeed's 16-bit wrapper, i.e. fp32 master weights
@@ -63,18 +64,45 @@ __global__ __launch_bounds__(256) void adam_sqnorm_k(float* __restrict__ partial
     }
 }
 
+// Large models: with hundreds of thousands of chunks "every block re-adds every partial" is quadratic (1.3 B parameters: 700 k
+// blocks x 700 k loads - measured 29 ms for a 360 M-parameter model where the update itself takes 3).  Above OPT_READD_MAX
+// chunks one block sums the partials once, in a fixed order (thread-strided, then the block tree: deterministic), and leaves
+// the total in partial[0] for the update kernel.
+constexpr int OPT_READD_MAX = 16384;
+
+__global__ __launch_bounds__(1024) void adam_norm_reduce_k(float* __restrict__ partial, int nchunks) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nchunks; i += 1024) acc += partial[i];
+    acc = wave_sum(acc);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();  // (also: every thread has read its partials before partial[0] is overwritten)
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        partial[0] = t;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adam_update_k(u16* const* __restrict__ params, float* __restrict__ master,
                                                      float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                      float* __restrict__ grad_norm_out, const float* __restrict__ partial,
                                                      int nchunks, const int* __restrict__ step, const AdamChunk* __restrict__ chunks,
                                                      const u16* const* __restrict__ grads, float lr, const float* __restrict__ lr_dev,
-                                                     float b1, float b2, float eps, float wd, float max_norm, int bias_correction) {
+                                                     float b1, float b2, float eps, float wd, float max_norm, int bias_correction,
+                                                     int pre_reduced) {
     __shared__ float red[4];
     __shared__ float sh[4];
-    // global norm: every block adds the same partials in the same order
+    // global norm: every block adds the same partials in the same order (or reads the total adam_norm_reduce_k left)
     float acc = 0.f;
-    for (int i = threadIdx.x; i < nchunks; i += 256) acc += partial[i];
+    if (pre_reduced) {
+        if (threadIdx.x == 0) acc = partial[0];
+    } else {
+        for (int i = threadIdx.x; i < nchunks; i += 256) acc += partial[i];
+    }
     const float total = block_sum_256(acc, red);
     if (threadIdx.x == 0) {
         const float norm = sqrtf(total);
@@ -176,9 +204,14 @@ extern "C" int mm_adam_step(void* const* params, const void* const* grads, float
         using T = decltype(t);
         adam_sqnorm_k<T><<<nchunks, 256, 0, st>>>(partial, step, (const AdamChunk*)chunks, (const u16* const*)grads);
         MM_CHECK_LAUNCH();
+        const int pre_reduced = nchunks > OPT_READD_MAX;
+        if (pre_reduced) {
+            adam_norm_reduce_k<<<1, 1024, 0, st>>>(partial, nchunks);
+            MM_CHECK_LAUNCH();
+        }
         adam_update_k<T><<<nchunks, 256, 0, st>>>((u16* const*)params, master, exp_avg, exp_avg_sq, grad_norm_out, partial, nchunks,
                                                   step, (const AdamChunk*)chunks, (const u16* const*)grads, lr, lr_dev, beta1, beta2, eps,
-                                                  weight_decay, max_grad_norm, bias_correction);
+                                                  weight_decay, max_grad_norm, bias_correction, pre_reduced);
         MM_CHECK_LAUNCH();
         return (int)MM_OK;
     });
