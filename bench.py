@@ -178,7 +178,8 @@ def main():
     # FusedAdam (fp32 master weights + moments) with the engine's global-norm clipping folded in: magma_setup.yml:38-45,
     # gradient_clipping: 1.0 (magma_pythia_410M.yml:57), megatron/training.py:571-580
     from multimodal_amd.optim import FusedAdam
-    opt = FusedAdam(params, lr=8e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+    opt = FusedAdam(params, lr=cfg.get("lr", 8e-4), betas=(0.9, 0.95), eps=1e-8, weight_decay=cfg.get("weight_decay", 0.0),
+                    max_grad_norm=1.0)
     batches = [harness.synthetic_batch(cfg, device, seed=1000 * dp_rank + i) for i in range(4)]  # one batch per TP group
     dp_group = mpu.get_data_parallel_group()
 

@@ -276,8 +276,12 @@ int gemm_pp_tile(int M, int N, int K, int lda, int ldb) {
     // 62 / 88 / 75 / 66.5; N=1024 K=1024: 19 / 28 / 24 / 20; N=50304 K=1024: 986 / 807 / 806 / 1116.  So: 256x256 tiles from
     // 1.5 rounds of the 256 CUs up; the N = h class (128 tiles of 256x256) stays on the 128x128 kernel, which two workgroups
     // per CU keep ahead of the 256x128 variant here.
+    // Other widths (h = 512, 2304 / TP 2, 4096 / TP 8; same tool, custom shapes): the 256x256 tile also wins at 192 and 256
+    // tiles (N=1536 K=4096: 84 vs 102 us on the 128x128 kernel; N=2048 K=512: 21 vs 24) and loses when the last round is
+    // mostly empty (288 tiles, N=2304 K=4608: 191 vs 180).  So: at least 3/4 of a round, and rounds at least 70 % full.
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    return t256 >= 384 ? 256 : 0;
+    const long rounds = (t256 + 255) / 256;
+    return (t256 >= 192 && 10 * t256 >= 7 * 256 * rounds) ? 256 : 0;
 }
 
 int gemm_pp_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,

@@ -18,35 +18,37 @@ from . import mpu
 from .checkpointing import checkpoint_policy
 from .model import LayerNorm, ParallelTransformerLayer, add_adapters, gpt2_attention_mask_func
 
+# lr / weight_decay: the YAML's optimizer block and weight-decay key (magma_pythia_410M.yml takes magma_setup.yml:38-45);
+# betas (0.9, 0.95), eps 1e-8 and gradient_clipping 1.0 are the same in all of them (tests/golden/configs.json)
 CONFIGS = {
     # configs/magma_pythia_410M.yml:5-33 + configs/magma_setup.yml:50-51 (micro-batch 4)
     "magma_pythia_410M": dict(hidden_size=1024, num_attention_heads=16, num_layers=24, seq_length=2048, rotary_pct=0.25,
                               gpt_j_residual=True, bias_gelu_fusion=True, scaled_upper_triang_masked_softmax_fusion=True,
                               add_adapters=True, adapter_downsample_factor=8, freeze_lm=True, micro_batch=4,
-                              padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1),
+                              padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1, lr=8e-4, weight_decay=0.0),
     # configs/19M.yml:6-17 (text-only plumbing config)
     "19M": dict(hidden_size=512, num_attention_heads=8, num_layers=6, seq_length=2048, rotary_pct=1.0,
                 gpt_j_residual=False, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
                 add_adapters=False, adapter_downsample_factor=8, freeze_lm=False, micro_batch=4,
-                padded_vocab_size=50304, encoder_out_dim=0, prefix_len=0, image_embed_dropout_prob=0.0),
+                padded_vocab_size=50304, encoder_out_dim=0, prefix_len=0, image_embed_dropout_prob=0.0, lr=1e-3, weight_decay=0.1),
     # configs/summit-70m-openclipH.yml:16-33 (no adapter_downsample_factor key: the default, 4 - neox_args.py:98)
     "summit-70m-openclipH": dict(hidden_size=512, num_attention_heads=8, num_layers=6, seq_length=2048, rotary_pct=0.25,
                                  gpt_j_residual=True, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
                                  add_adapters=True, adapter_downsample_factor=4, freeze_lm=True, micro_batch=4,
-                                 padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1),
+                                 padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1, lr=1e-3, weight_decay=0.1),
     # configs/summit-1-3B.yml:5-33 - BASELINE.json configs[3] runs it at tensor-parallel 2 x data-parallel 4 (the YAML's own
     # model-parallel-size 3 / pipe 2 is a Summit layout; 18 heads % 2 == 0 and 2304 % 2 == 0 satisfy transformer.py:210-217).
     # No adapters, LM trainable, image prefix on (openclip-H -> 1 prefix token)
     "summit-1-3B": dict(hidden_size=2304, num_attention_heads=18, num_layers=24, seq_length=2048, rotary_pct=1.0,
                         gpt_j_residual=False, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
                         add_adapters=False, adapter_downsample_factor=8, freeze_lm=False, micro_batch=4,
-                        padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1),
+                        padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1, lr=2e-4, weight_decay=0.1),
     # configs/6-7B.yml:5-22 shape as a multimodal model (BASELINE.json configs[4]: tensor-parallel 8): image prefix as in the
     # other multimodal configs, LM trainable
     "6-7B": dict(hidden_size=4096, num_attention_heads=32, num_layers=32, seq_length=2048, rotary_pct=1.0,
                  gpt_j_residual=False, bias_gelu_fusion=False, scaled_upper_triang_masked_softmax_fusion=False,
                  add_adapters=False, adapter_downsample_factor=8, freeze_lm=False, micro_batch=4,
-                 padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1),
+                 padded_vocab_size=50304, encoder_out_dim=1024, prefix_len=1, image_embed_dropout_prob=0.1, lr=1.2e-4, weight_decay=0.1),
     # a small MAGMA stack with everything the 410M recipe has (adapters of a shape the fused adapter kernel takes, frozen LM,
     # image prefix with dropout): what tests/test_graph_gpu.py captures
     "tiny_magma": dict(hidden_size=512, num_attention_heads=8, num_layers=2, seq_length=256, rotary_pct=0.25,

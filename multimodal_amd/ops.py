@@ -330,7 +330,10 @@ def gemm_tn(a, b, with_colsum=False):
         raise RuntimeError("gemm_tn: row counts differ")
     lib = get_lib()
     splits = lib.mm_gemm_tn_splits(M, N, Kp)
-    if splits == 0:
+    # Model-sized weight gradients (an LM that is NOT frozen: [9216, 2304] at summit-1-3B) are GEMMs of hundreds of GFLOP: two
+    # HBM transposes (16-byte-access kernel, ~0.1 ms for the [8192, 9216] activation) and the ping-pong NT kernel at 1.2-1.3 PF
+    # beat the split-K kernel's ~0.5 PF there; the adapters' [128, 1024] gradients stay on the split-K kernel.
+    if splits == 0 or (N * Kp >= (1 << 21) and M >= 512):
         c = gemm_nt(transpose2d(a), transpose2d(b))
         return (c, colsum(a)) if with_colsum else c
     c = torch.empty(N, Kp, dtype=a.dtype, device=a.device)

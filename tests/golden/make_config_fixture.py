@@ -24,6 +24,10 @@ for n in NAMES:
     d = {k.replace("-", "_"): v for k, v in yaml.safe_load(open(os.path.join(REF, n + ".yml"))).items()}
     row = {k: d.get(k, DEFAULTS.get(k)) for k in KEYS}
     row["train_micro_batch_size_per_gpu"] = d.get("train_micro_batch_size_per_gpu", setup["train_micro_batch_size_per_gpu"])
+    opt = d.get("optimizer", setup["optimizer"])  # magma_pythia_410M.yml has none of its own: magma_setup.yml:38-45
+    row["optimizer"] = {"type": opt["type"], "lr": opt["params"]["lr"], "betas": opt["params"]["betas"], "eps": opt["params"]["eps"]}
+    row["weight_decay"] = d.get("weight_decay", 0.0)
+    row["gradient_clipping"] = d.get("gradient_clipping", 1.0)
     out[n] = row
 with open(os.path.join(HERE, "configs.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)

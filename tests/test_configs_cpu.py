@@ -19,6 +19,9 @@ def test_harness_config_matches_reference_yaml(name):
         assert cfg[k] == ref[k], (name, k, cfg[k], ref[k])
     assert cfg["rotary_pct"] == pytest.approx(ref["rotary_pct"])
     assert cfg["micro_batch"] == ref["train_micro_batch_size_per_gpu"]
+    assert cfg["lr"] == pytest.approx(ref["optimizer"]["lr"]) and cfg["weight_decay"] == pytest.approx(ref["weight_decay"])
+    assert ref["optimizer"]["type"] == "Adam" and ref["optimizer"]["betas"] == [0.9, 0.95] and ref["optimizer"]["eps"] == 1e-8
+    assert ref["gradient_clipping"] == 1.0   # what bench.py passes to FusedAdam for every config
     assert ref["pos_emb"] == "rotary" and ref["hidden_dropout"] == 0 and ref["attention_dropout"] == 0
     if cfg["add_adapters"]:
         assert cfg["adapter_downsample_factor"] == ref["adapter_downsample_factor"]

@@ -241,6 +241,9 @@ def test_colsum_transpose_add(ops, cuda_device):
     assert (got - ref).abs().max() <= 2 ** -7 * ref.abs().max()
     xt = ops.transpose2d(x.to(cuda_device))
     assert torch.equal(xt.cpu(), x.t().contiguous())
+    for r, c in ((64, 72), (8, 8), (1001, 383), (2048, 2304), (520, 4104), (7, 16)):  # 16-byte kernel, partial tiles, ragged fallback
+        t = torch.randn(r, c).bfloat16()
+        assert torch.equal(ops.transpose2d(t.to(cuda_device)).cpu(), t.t().contiguous()), (r, c)
     y = torch.randn(1000, 384).bfloat16()
     z = torch.randn(1000, 384).bfloat16()
     assert torch.equal(ops.add(x.to(cuda_device), y.to(cuda_device)).cpu(), x + y)
@@ -479,7 +482,7 @@ def test_cross_entropy_fwd_grad_rejects_rows_beyond_registers(ops, cuda_device):
 # ------------------------------------------------------------------ weight-gradient GEMM (TN, split-K)
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,Kp", [(64, 128, 128), (256, 128, 256), (8192, 128, 1024), (8192, 1024, 128), (1024, 384, 128),
-                                    (192, 128, 128), (100, 128, 128), (256, 96, 128)])
+                                    (192, 128, 128), (100, 128, 128), (256, 96, 128), (2048, 2304, 1024)])
 def test_gemm_tn(ops, cuda_device, dt, M, N, Kp):
     from multimodal_amd._lib import get_lib
     torch.manual_seed(M + N + Kp)

@@ -13,8 +13,12 @@ KINDS = [("128x128", {"MM_GEMMPP": "-1", "MM_GEMM256": "-1"}), ("256x256", {"MM_
 shapes = [("h4h gelu", T, 4 * H, H, _lib.EPI_BIAS_GELU_TANH), ("4hh dx gelu'", T, 4 * H, H, _lib.EPI_GELU_TANH_BWD),
           ("qkv fwd", T, 3 * H, H, _lib.EPI_BIAS), ("4hh fwd", T, H, 4 * H, _lib.EPI_NONE), ("dense", T, H, H, _lib.EPI_NONE),
           ("qkv dx", T, H, 3 * H, _lib.EPI_NONE), ("lm head", T, 50304, H, _lib.EPI_NONE), ("head dx", T, H, 50304, _lib.EPI_NONE)]
-if len(sys.argv) > 1:
-    shapes = [s for s in shapes if any(a in s[0] for a in sys.argv[1:])]
+import re
+custom = [a for a in sys.argv[1:] if re.fullmatch(r"\d+,\d+,\d+", a)]   # M,N,K triples: plain epilogue
+names = [a for a in sys.argv[1:] if a not in custom]
+if names or custom:
+    shapes = [s for s in shapes if any(a in s[0] for a in names)]
+    shapes += [("custom", *(int(v) for v in c.split(",")), _lib.EPI_NONE) for c in custom]
 for name, M, N, K, epi in shapes:
     a = [rnd(M, K) for _ in range(2)]
     w = [rnd(N, K, scale=0.02) for _ in range(2)]
