@@ -465,23 +465,26 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
                 } else {
                     // packed fp32 math, two scores per VALU issue; the causal select is a separate, wave-uniformly
                     // branched pass that only the tiles on this wave's diagonal execute
-                    const f32x2 sc2 = {scale_log2e, scale_log2e}, l2 = {lse2, lse2}, d2 = {dlt, dlt};
-                    f32x2 pp[8];
+                    // scalar fp32 on purpose: v_pk_*_f32 serialise with the partner wave's MFMAs, plain VALU overlaps them
+                    // (tools/ubench/coissue.hip)
+                    float pp[16];
+                    const float nl = -lse2;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f32x2 e = f32x2{sacc[2 * i], sacc[2 * i + 1]} * sc2 - l2;
-                        pp[i] = f32x2{fast_exp2(e[0]), fast_exp2(e[1])};
+                    for (int i = 0; i < 16; ++i) {
+                        float e = __builtin_fmaf(sacc[i], scale_log2e, nl);
+                        asm volatile("" : "+v"(e));
+                        pp[i] = fast_exp2(e);
                     }
                     if (kv0 + 32 * t + 31 > wave_first) {  // wave-uniform
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
-                            if (kv0 + 32 * t + acc_row(i, hh) > qrow) pp[i >> 1][i & 1] = 0.f;
+                            if (kv0 + 32 * t + acc_row(i, hh) > qrow) pp[i] = 0.f;
                     }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f32x2 ds2 = pp[i] * (f32x2{dpacc[2 * i], dpacc[2 * i + 1]} - d2);  // dS / scale (applied once at the end)
-                        sacc[2 * i] = ds2[0];
-                        sacc[2 * i + 1] = ds2[1];
+                    for (int i = 0; i < 16; ++i) {
+                        float dsv = pp[i] * (dpacc[i] - dlt);  // dS / scale (applied once at the end)
+                        asm volatile("" : "+v"(dsv));
+                        sacc[i] = dsv;
                     }
                 }
                 mfma_prio(1);
@@ -624,16 +627,15 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                 const bool need_mask = (wave_first + 31 > q0t + 32 * t) || (q0t + 32 * t + 32 > s);
                 if (MODE == 0) {
                     // packed fp32 math, two scores per VALU issue; the causal select is its own wave-uniformly branched pass
-                    const f32x2 sc2 = {scale_log2e, scale_log2e};
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int ql = 32 * t + 8 * g4 + 4 * hh;  // local row of register 4*g4
                         const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + ql);
 #pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            const f32x2 x = f32x2{sacc[4 * g4 + e], sacc[4 * g4 + e + 1]} * sc2 - f32x2{l4[e], l4[e + 1]};
-                            pv[4 * g4 + e] = fast_exp2(x[0]);
-                            pv[4 * g4 + e + 1] = fast_exp2(x[1]);
+                        for (int e = 0; e < 4; ++e) {  // scalar fp32 on purpose (see the dQ kernel)
+                            float x = __builtin_fmaf(sacc[4 * g4 + e], scale_log2e, -l4[e]);
+                            asm volatile("" : "+v"(x));
+                            pv[4 * g4 + e] = fast_exp2(x);
                         }
                     }
                     if (need_mask) {
@@ -648,11 +650,11 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                         const int ql = 32 * t + 8 * g4 + 4 * hh;
                         const f32x4 d4 = *reinterpret_cast<const f32x4*>(sl + 64 + ql);
 #pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
+                        for (int e = 0; e < 4; ++e) {
                             const int i = 4 * g4 + e;
-                            const f32x2 ds2 = f32x2{pv[i], pv[i + 1]} * (f32x2{dpacc[i], dpacc[i + 1]} - f32x2{d4[e], d4[e + 1]});
-                            sacc[i] = ds2[0];  // dS / scale; the scale is applied once to dK at the end
-                            sacc[i + 1] = ds2[1];
+                            float dsv = pv[i] * (dpacc[i] - d4[e]);  // dS / scale; the scale is applied once to dK at the end
+                            asm volatile("" : "+v"(dsv));
+                            sacc[i] = dsv;
                         }
                     }
                 } else {
