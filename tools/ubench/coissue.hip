@@ -37,6 +37,31 @@ __global__ __launch_bounds__(512, 1) void k(float* out, long long* cyc, int nseg
                 } else if (KIND == 1) {  // v_exp_f32
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { v[j] = __builtin_amdgcn_exp2f(v[j]); asm volatile("" : "+v"(v[j])); }
+                } else if (KIND == 3) {  // v_cvt_pk_bf16_f32
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+                        bf2 c0 = bf2{(__bf16)v[j], (__bf16)v[j + 1]}, c1 = bf2{(__bf16)v[j + 1], (__bf16)v[j]};
+                        unsigned u0, u1; __builtin_memcpy(&u0, &c0, 4); __builtin_memcpy(&u1, &c1, 4);
+                        asm volatile("" : "+v"(u0)); asm volatile("" : "+v"(u1));
+                        v[j] = __uint_as_float(u0 & 0xffff0000u); v[j + 1] = __uint_as_float(u1 << 16);
+                        asm volatile("" : "+v"(v[j])); asm volatile("" : "+v"(v[j + 1]));
+                    }
+                } else if (KIND == 4) {  // v_max3_f32
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { v[j] = fmaxf(fmaxf(v[j], v[(j + 1) & 7]), v[(j + 3) & 7]); asm volatile("" : "+v"(v[j])); }
+                } else if (KIND == 5) {  // v_cmp + v_cndmask
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) { v[j] = (v[j + 1] > (float)i) ? v[j] : -1.0f; asm volatile("" : "+v"(v[j])); v[j + 1] = (v[j] > (float)s) ? v[j + 1] : 2.0f; asm volatile("" : "+v"(v[j + 1])); }
+                } else if (KIND == 6) {  // v_permlane32_swap
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j]), false, false);
+                        v[j] = __uint_as_float(r[0]) + 0.0f; asm volatile("" : "+v"(v[j]));
+                    }
+                } else if (KIND == 7) {  // v_mov_b32 (register copies)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { float t = v[(j + 1) & 7]; asm volatile("v_mov_b32 %0, %1" : "=v"(v[j]) : "v"(t)); }
                 } else {  // v_pk_fma_f32 (4 per 8 "instructions": counts as 4 issues)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { p[j] = p[j] * f32x2{1.0001f, 0.9999f} + f32x2{0.5f, 0.25f}; asm volatile("" : "+v"(p[j])); }
@@ -69,16 +94,16 @@ int main() {
     float* out; long long* cyc;
     hipMalloc(&out, 4096); hipMalloc(&cyc, 8);
     const int nseg = 2000, nm = 16;
-    const char* names[3] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32"};
+    const char* names[8] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32", "v_cvt_pk_bf16", "v_max3_f32", "v_cmp+cndmask", "permlane32_swap", "v_mov_b32"};
     printf("cycles are s_memrealtime-independent shader clocks (readcyclecounter) per segment; 16 MFMA 32x32x16 per segment in group A\n");
-    for (int nv = 64; nv <= 192; nv += 64) {
+    for (int nv = 128; nv <= 128; nv += 64) {
         double a = run<0, true, false, false>(nseg, nm, nv, out, cyc);
         printf("nv=%d  A only %.0f\n", nv, a);
 #define ROW(K)                                                                                                        \
         printf("   %-14s B only %.0f   A+B %.0f   A+B (groups swapped: B on the older waves) %.0f\n", names[K],        \
                run<K, false, true, false>(nseg, nm, nv, out, cyc), run<K, true, true, false>(nseg, nm, nv, out, cyc), \
                run<K, true, true, true>(nseg, nm, nv, out, cyc));
-        ROW(0) ROW(1) ROW(2)
+        ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7)
     }
     return 0;
 }
