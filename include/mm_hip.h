@@ -68,6 +68,15 @@ int mm_layernorm_bwd(void* dx, float* dwdb_partial, const void* dy, const void* 
 /* out_k[h] (dtype) = sum over nblk of partial[:, k, :], k = 0..nvec-1; outs[k] may be NULL. */
 int mm_layernorm_bwd_finalize(void* const* outs, const float* dwdb_partial, int nblk, int nvec, int h,
                               int dtype, void* stream);
+/* The stack's final LayerNorm (NormPipe, megatron/model/transformer.py:828-839) fused with _post_transformer_block's
+ * [s, b, h] -> [b, s, h] transpose(0, 1).contiguous() (megatron/model/gpt2_model.py:80-85): x is read in [s, b, h] order,
+ * y / mean / rstd are written in [b, s, h] order - no transposed copy of the activation exists.  The backward takes dy in
+ * [b, s, h] order, optionally multiplied by the DEVICE scalar dy_scale[0] (a fused loss node's upstream gradient), and
+ * writes dx in [s, b, h] order; dwdb_partial as in mm_layernorm_bwd (nvec = 2). */
+int mm_layernorm_fwd_sb(void* y, float* mean, float* rstd, const void* x, const void* w, const void* b, int s, int bsz,
+                        int h, float eps, int dtype, void* stream);
+int mm_layernorm_bwd_sb(void* dx, float* dwdb_partial, const void* dy, const float* dy_scale, const void* x, const void* w,
+                        const float* mean, const float* rstd, int s, int bsz, int h, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ rotary
  * Replaces apply_rotary_pos_emb{,_torch} + the slicing/cat around it
@@ -273,6 +282,15 @@ int mm_cross_entropy_bwd(void* dlogits, const void* logits, const int64_t* label
 int mm_cross_entropy_fwd_grad(float* loss, float* lse, void* logits, const int64_t* labels, const float* row_weight,
                               int T, int V, int dtype, void* stream);
 int mm_cross_entropy_fwd_grad_max_v(void);
+/* The masked mean around the per-token losses (megatron/model/gpt2_model.py:64-70: `loss_mask.view(-1)`,
+ * `torch.sum(losses.view(-1) * loss_mask) / loss_mask.sum()`), fp32 [T] vectors, one block each, fixed summation order:
+ * mm_loss_mask_weights: den[0] = sum(loss_mask), row_weight[t] = loss_mask[t] / den (mm_cross_entropy_fwd_grad's weights);
+ * mm_masked_mean: out[0] = sum(losses * loss_mask) / den[0]. */
+int mm_loss_mask_weights(float* row_weight, float* den, const float* loss_mask, int T, void* stream);
+int mm_masked_mean(float* out, const float* losses, const float* loss_mask, const float* den, int T, void* stream);
+/* out = x * scalar[0] on n 16-bit elements (scalar: DEVICE fp32): applies the upstream gradient of a fused loss node
+ * (autograd's grad_output of the scalar loss, megatron/training.py:706-712 `model.backward(loss)`) without a host sync. */
+int mm_scale_dev(void* out, const void* x, const float* scalar, size_t n, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ embedding + image prefix
  * The step in front of the first layer in one pass: word-embedding gather, `cat((image_prefix, text[:, :s-P]), dim=1)` and
@@ -282,6 +300,23 @@ int mm_cross_entropy_fwd_grad_max_v(void);
  * tokens [b, s] int64 (ids clamped to [0, V)). */
 int mm_embed_prefix(void* out, const void* table, const int64_t* tokens, const void* prefix, int s, int b, int h, int P,
                     int V, void* stream);
+/* ImagePrefix.forward behind its encoder (megatron/model/image_prefix.py:232-252): proj = nn.Linear(enc_dim, out_dim),
+ * nn.Dropout(p), nn.LayerNorm(out_dim) on x [rows = b * P, enc_dim] in ONE launch for the few rows of a step (rows <= 16; the
+ * pooled openclip-H encoder gives P = 1, image_prefix.py:106).  out [rows, out_dim]; ln_in (optional) receives the LayerNorm's
+ * input (post-dropout), keep_mask (optional, bytes, 1 = kept) the dropout mask and mean / rstd the statistics - what the
+ * backward (mm_layernorm_bwd, mm_dropout_bwd, the GEMM entry points) needs.  Dropout draws from the device-resident Philox
+ * state exactly as mm_bias_dropout_add_devrng(rng_state, offset) does on the same [rows, out_dim] tensor.  workspace:
+ * mm_prefix_tail_workspace_bytes(rows, out_dim) bytes of device memory (its first 256 bytes are zeroed on `stream` by the
+ * call: the ticket of the workgroup that arrives last and normalises the rows).  Shapes outside mm_prefix_tail_supported
+ * return MM_EINVAL: run mm_gemm_nt + mm_bias_dropout_add + mm_layernorm_fwd instead. */
+int mm_prefix_tail_supported(int rows, int enc_dim, int out_dim);
+size_t mm_prefix_tail_workspace_bytes(int rows, int out_dim);
+int mm_prefix_tail_fwd(void* out, void* ln_in, uint8_t* keep_mask, float* mean, float* rstd, const void* x, const void* w,
+                       const void* bias, const void* ln_w, const void* ln_b, void* workspace, int rows, int enc_dim, int out_dim,
+                       float eps, float p, int training, const uint64_t* rng_state, uint64_t offset, int dtype, void* stream);
+/* dx = keep_mask ? g / (1 - p) : 0 (n elements, n % 8 == 0): backward of nn.Dropout for a mask written by
+ * mm_prefix_tail_fwd / mm_bias_dropout_add. */
+int mm_dropout_bwd(void* dx, const void* g, const uint8_t* keep_mask, size_t n, float p, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ optimizer step (part of the timed step)
  * Mixed-precision Adam with global-norm gradient clipping over a list of 16-bit tensors, two launches per step.  States

@@ -32,6 +32,8 @@ PROTOTYPES = {
     "mm_layernorm_bwd_nblk": (c_int, [c_int]),
     "mm_layernorm_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p]),
     "mm_layernorm_bwd_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mm_layernorm_fwd_sb": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "mm_layernorm_bwd_sb": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_void_p]),
     "mm_rotary_qk_inplace": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "mm_bias_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mm_bias_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -67,7 +69,14 @@ PROTOTYPES = {
     "mm_cross_entropy_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mm_cross_entropy_fwd_grad": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p]),
     "mm_cross_entropy_fwd_grad_max_v": (c_int, []),
+    "mm_loss_mask_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mm_masked_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mm_scale_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "mm_embed_prefix": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "mm_prefix_tail_supported": (c_int, [c_int, c_int, c_int]),
+    "mm_prefix_tail_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mm_prefix_tail_fwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, c_u64, c_int, c_void_p]),
+    "mm_dropout_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p]),
     "mm_adam_chunk_elems": (c_int, []),
     "mm_adam_step": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p] + [c_float] * 5 + [c_int, c_int, c_void_p]),
     "mm_debug_gemm256": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),

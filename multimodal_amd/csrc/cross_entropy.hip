@@ -180,6 +180,50 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
+// ---- the masked mean around the per-token losses (megatron/model/gpt2_model.py:52-70: sum(losses * mask) / mask.sum()) as
+// two one-block launches instead of seven framework kernels: den = sum(mask), w[t] = mask[t] / den before the loss kernel
+// (its per-row gradient weight), and loss = sum(losses * mask) / den after it.  Fixed summation order: deterministic.
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // red may still be read from a previous call
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += red[k];
+    return t;
+}
+__global__ __launch_bounds__(1024) void loss_mask_weights_k(float* __restrict__ w, float* __restrict__ den_out,
+                                                            const float* __restrict__ mask, int T) {
+    __shared__ float red[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < T; i += 1024) a += mask[i];
+    const float den = block_sum_1024(a, red);
+    const float inv = 1.0f / den;
+    for (int i = threadIdx.x; i < T; i += 1024) w[i] = inv * mask[i];
+    if (threadIdx.x == 0) den_out[0] = den;
+}
+__global__ __launch_bounds__(1024) void masked_mean_k(float* __restrict__ out, const float* __restrict__ losses,
+                                                      const float* __restrict__ mask, const float* __restrict__ den, int T) {
+    __shared__ float red[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < T; i += 1024) a += losses[i] * mask[i];
+    const float tot = block_sum_1024(a, red);
+    if (threadIdx.x == 0) out[0] = tot / den[0];
+}
+// out = x * (*scalar): applies a fused loss node's upstream gradient (a device scalar) to a parameter gradient
+template <typename T>
+__global__ __launch_bounds__(256) void scale_dev_k(u16* __restrict__ out, const u16* __restrict__ x, const float* __restrict__ scalar, size_t n8) {
+    const float sc = *scalar;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        float v[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(x + i * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= sc;
+        *reinterpret_cast<u32x4*>(out + i * 8) = pack8<T>(v);
+    }
+}
+
 }  // namespace mm
 
 using namespace mm;
@@ -232,3 +276,33 @@ extern "C" int mm_cross_entropy_fwd_grad(float* loss, float* lse, void* logits, 
         return (int)MM_OK;
     });
 }
+
+extern "C" int mm_loss_mask_weights(float* row_weight, float* den, const float* loss_mask, int T, void* stream) {
+    MM_CHECK_ARG(row_weight && den && loss_mask && T > 0, "mm_loss_mask_weights: bad arguments");
+    loss_mask_weights_k<<<1, 1024, 0, (hipStream_t)stream>>>(row_weight, den, loss_mask, T);
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
+extern "C" int mm_masked_mean(float* out, const float* losses, const float* loss_mask, const float* den, int T, void* stream) {
+    MM_CHECK_ARG(out && losses && loss_mask && den && T > 0, "mm_masked_mean: bad arguments");
+    masked_mean_k<<<1, 1024, 0, (hipStream_t)stream>>>(out, losses, loss_mask, den, T);
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
+extern "C" int mm_scale_dev(void* out, const void* x, const float* scalar, size_t n, int dtype, void* stream) {
+    MM_CHECK_ARG(out && x && scalar, "mm_scale_dev: null pointer");
+    MM_CHECK_ARG(n % 8 == 0 && aligned16(out) && aligned16(x), "mm_scale_dev: n must be a multiple of 8 and the tensors 16-byte aligned");
+    const size_t n8 = n / 8;
+    if (n8 == 0) return MM_OK;
+    size_t g = (n8 + 255) / 256;
+    if (g > 2048) g = 2048;
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using TT = decltype(t);
+        scale_dev_k<TT><<<dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream>>>((u16*)out, (const u16*)x, scalar, n8);
+        MM_CHECK_LAUNCH();
+        return (int)MM_OK;
+    });
+}
+

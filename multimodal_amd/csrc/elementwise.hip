@@ -2,6 +2,7 @@
 // bias-GeLU fwd/bwd, bias-dropout-add, column sums (bias gradients), 2-D transpose, add.
 // All kernels move 16 bytes per lane per access and grid-stride over <= 2048 blocks.
 #include "common.h"
+#include "philox.h"
 
 namespace mm {
 
@@ -94,26 +95,6 @@ __global__ __launch_bounds__(256) void bias_gelu_k(u16* __restrict__ out, const 
 }
 
 // ------------------------------------------------------------------------------------ bias-dropout-add
-struct Philox {
-    // Philox4x32-10 (Salmon et al. 2011): counter (4x32), key (2x32)
-    static __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
-    }
-    static __device__ __forceinline__ void gen(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi, uint32_t (&out)[4]) {
-        uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)};
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            round(c, k0, k1);
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) out[j] = c[j];
-    }
-};
-
 // out = residual + dropout(x + bias); eager rounding: (x+bias) rounded, scaled/masked, rounded, + residual rounded.
 template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void bias_dropout_add_k(u16* __restrict__ out, const u16* __restrict__ x,

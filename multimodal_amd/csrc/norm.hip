@@ -10,17 +10,22 @@
 
 namespace mm {
 
+// Transposed-input variants (final LayerNorm of the stack: the layers' [s, b, h] activation is read by stride and the output,
+// statistics and incoming gradient are in [b, s, h] order - _post_transformer_block's transpose(0, 1).contiguous(),
+// megatron/model/gpt2_model.py:80-85, without the copy): output row r = bi * s + si reads input row si * b + bi.
+__device__ __forceinline__ int in_row_of(int row, int tr_s, int tr_b) { return tr_b ? (row % tr_s) * tr_b + row / tr_s : row; }
+
 template <typename T, int ITERS, bool DUAL>
 __global__ __launch_bounds__(256) void layernorm_fwd_k(u16* __restrict__ y, u16* __restrict__ y2, float* __restrict__ mean_o,
                                                        float* __restrict__ rstd_o, const u16* __restrict__ x,
                                                        const u16* __restrict__ w, const u16* __restrict__ b,
                                                        const u16* __restrict__ w2, const u16* __restrict__ b2, int rows,
-                                                       int h, float eps) {
+                                                       int h, float eps, int tr_s = 0, int tr_b = 0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nchunk = h >> 3;
-    const u16* xr = x + (size_t)row * h;
+    const u16* xr = x + (size_t)in_row_of(row, tr_s, tr_b) * h;
     float v[ITERS][8];
     float sum = 0.f;
     // the affine parameters are requested together with the row (their latency hides behind the two reductions)
@@ -97,13 +102,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_k(u16* __restrict__ dx, 
                                                           const u16* __restrict__ dy2, const u16* __restrict__ dres,
                                                           const u16* __restrict__ x, const u16* __restrict__ w,
                                                           const u16* __restrict__ w2, const float* __restrict__ mean_i,
-                                                          const float* __restrict__ rstd_i, int rows, int h) {
+                                                          const float* __restrict__ rstd_i, int rows, int h, int tr_s = 0,
+                                                          int tr_b = 0, const float* __restrict__ dy_scale = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nchunk = h >> 3;
-    const size_t ro = (size_t)row * h;
+    const size_t ro = (size_t)row * h;                            // dy / dy2 / statistics: output order
+    const size_t xo = (size_t)in_row_of(row, tr_s, tr_b) * h;     // x / dx / dres: input order
     const float mean = mean_i[row], rstd = rstd_i[row];
+    const float gsc = dy_scale ? *dy_scale : 1.0f;  // upstream scalar gradient of a fused loss node (device scalar, no host sync)
     float g[ITERS][8], xh[ITERS][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -111,11 +119,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_k(u16* __restrict__ dx, 
         const int c = it * 64 + lane;
         if (c < nchunk) {
             float a[8], wv[8];
-            unpack8<T>(*reinterpret_cast<const u32x4*>(x + ro + c * 8), xh[it]);
+            unpack8<T>(*reinterpret_cast<const u32x4*>(x + xo + c * 8), xh[it]);
             unpack8<T>(*reinterpret_cast<const u32x4*>(dy + ro + c * 8), a);
             unpack8<T>(*reinterpret_cast<const u32x4*>(w + c * 8), wv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[it][j] = a[j] * wv[j];
+            for (int j = 0; j < 8; ++j) g[it][j] = (dy_scale ? a[j] * gsc : a[j]) * wv[j];
             if (DUAL) {
                 unpack8<T>(*reinterpret_cast<const u32x4*>(dy2 + ro + c * 8), a);
                 unpack8<T>(*reinterpret_cast<const u32x4*>(w2 + c * 8), wv);
@@ -141,11 +149,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_k(u16* __restrict__ dx, 
             for (int j = 0; j < 8; ++j) o[j] = rstd * (g[it][j] - c1 - xh[it][j] * c2);
             if (RES) {
                 float r[8];
-                unpack8<T>(*reinterpret_cast<const u32x4*>(dres + ro + c * 8), r);
+                unpack8<T>(*reinterpret_cast<const u32x4*>(dres + xo + c * 8), r);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] += r[j];
             }
-            *reinterpret_cast<u32x4*>(dx + ro + c * 8) = pack8<T>(o);
+            *reinterpret_cast<u32x4*>(dx + xo + c * 8) = pack8<T>(o);
         }
     }
 }
@@ -156,7 +164,8 @@ template <typename T, bool DUAL>
 __global__ __launch_bounds__(64) void layernorm_bwd_param_k(float* __restrict__ partial, const u16* __restrict__ dy,
                                                             const u16* __restrict__ dy2, const u16* __restrict__ x,
                                                             const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-                                                            int rows, int h, int nblk) {
+                                                            int rows, int h, int nblk, int tr_s = 0, int tr_b = 0,
+                                                            const float* __restrict__ dy_scale = nullptr) {
     const int col = (blockIdx.x * 64 + threadIdx.x) * 8;
     const int blk = blockIdx.y;
     constexpr int NV = DUAL ? 4 : 2;
@@ -168,11 +177,16 @@ __global__ __launch_bounds__(64) void layernorm_bwd_param_k(float* __restrict__ 
     if (col < h) {
         const int per = (rows + nblk - 1) / nblk;
         const int r0 = blk * per, r1 = min(rows, r0 + per);
+        const float gsc = dy_scale ? *dy_scale : 1.0f;
         for (int r = r0; r < r1; ++r) {
             const float mean = mean_i[r], rstd = rstd_i[r];
             float xv[8], a[8];
-            unpack8<T>(*reinterpret_cast<const u32x4*>(x + (size_t)r * h + col), xv);
+            unpack8<T>(*reinterpret_cast<const u32x4*>(x + (size_t)in_row_of(r, tr_s, tr_b) * h + col), xv);
             unpack8<T>(*reinterpret_cast<const u32x4*>(dy + (size_t)r * h + col), a);
+            if (dy_scale) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] *= gsc;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 xv[j] = (xv[j] - mean) * rstd;
@@ -319,3 +333,55 @@ extern "C" int mm_layernorm_bwd_finalize(void* const* outs, const float* partial
         return (int)MM_OK;
     });
 }
+
+// ---- the stack's final LayerNorm without _post_transformer_block's copy (megatron/model/gpt2_model.py:80-85,
+// megatron/model/transformer.py:828-839): x is the layers' [s, b, h] activation, y / mean / rstd / dy are in [b, s, h] order.
+extern "C" int mm_layernorm_fwd_sb(void* y, float* mean, float* rstd, const void* x, const void* w, const void* b, int s, int bsz,
+                                   int h, float eps, int dtype, void* stream) {
+    MM_CHECK_ARG(y && x && w && b, "mm_layernorm_fwd_sb: null pointer");
+    MM_CHECK_ARG(s > 0 && bsz > 0 && h > 0 && (long)s * bsz < (1l << 31), "mm_layernorm_fwd_sb: s=%d b=%d h=%d", s, bsz, h);
+    MM_CHECK_ARG(h % 8 == 0 && h <= 8192, "mm_layernorm_fwd_sb: h=%d must be a multiple of 8 and <= 8192", h);
+    MM_CHECK_ARG(aligned16(y) && aligned16(x) && aligned16(w) && aligned16(b), "mm_layernorm_fwd_sb: pointers must be 16-byte aligned");
+    const int rows = s * bsz, iters = pick_iters(h);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((rows + 3) / 4), block(256);
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        MM_LN_ITERS_SWITCH(iters, {
+            layernorm_fwd_k<T, IT, false><<<grid, block, 0, st>>>((u16*)y, nullptr, mean, rstd, (const u16*)x, (const u16*)w,
+                                                                  (const u16*)b, nullptr, nullptr, rows, h, eps, s, bsz);
+        });
+        MM_CHECK_LAUNCH();
+        return (int)MM_OK;
+    });
+}
+
+// dx [s, b, h] from dy [b, s, h] (times the device scalar *dy_scale when given); dwdb_partial as mm_layernorm_bwd.
+extern "C" int mm_layernorm_bwd_sb(void* dx, float* dwdb_partial, const void* dy, const float* dy_scale, const void* x,
+                                   const void* w, const float* mean, const float* rstd, int s, int bsz, int h, int dtype,
+                                   void* stream) {
+    MM_CHECK_ARG(dx && dy && x && w && mean && rstd, "mm_layernorm_bwd_sb: null pointer");
+    MM_CHECK_ARG(s > 0 && bsz > 0 && h > 0 && (long)s * bsz < (1l << 31), "mm_layernorm_bwd_sb: s=%d b=%d h=%d", s, bsz, h);
+    MM_CHECK_ARG(h % 8 == 0 && h <= 8192, "mm_layernorm_bwd_sb: h=%d must be a multiple of 8 and <= 8192", h);
+    MM_CHECK_ARG(aligned16(dx) && aligned16(dy) && aligned16(x) && aligned16(w), "mm_layernorm_bwd_sb: pointers must be 16-byte aligned");
+    const int rows = s * bsz, iters = pick_iters(h);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((rows + 3) / 4), block(256);
+    const int nblk = mm_layernorm_bwd_nblk(rows);
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        MM_LN_ITERS_SWITCH(iters, {
+            layernorm_bwd_dx_k<T, IT, false, false><<<grid, block, 0, st>>>((u16*)dx, (const u16*)dy, nullptr, nullptr, (const u16*)x,
+                                                                            (const u16*)w, nullptr, mean, rstd, rows, h, s, bsz, dy_scale);
+        });
+        MM_CHECK_LAUNCH();
+        if (dwdb_partial) {
+            dim3 pg((h + 511) / 512, nblk), pb(64);
+            layernorm_bwd_param_k<T, false><<<pg, pb, 0, st>>>(dwdb_partial, (const u16*)dy, nullptr, (const u16*)x, mean, rstd, rows, h,
+                                                               nblk, s, bsz, dy_scale);
+            MM_CHECK_LAUNCH();
+        }
+        return (int)MM_OK;
+    });
+}
+

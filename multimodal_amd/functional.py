@@ -7,7 +7,8 @@ language model (reference `freeze_lm`, megatron/training.py:454-459) pays for th
 """
 import torch
 
-from . import _lib, ops
+from . import _lib, _streams, ops
+
 
 def weight_t(w):
     """Contiguous W^T ([in, out]) of a [out, in] weight.  Cached ON the weight object (so it dies with it) for FROZEN
@@ -18,9 +19,10 @@ def weight_t(w):
         return ops.transpose2d(w.detach())
     ent = getattr(w, "_mm_wt", None)
     if ent is not None and ent[0] == w.data_ptr() and ent[1] == w._version and ent[2].device == w.device:
+        _streams.wait(ent[3], w.device)  # filled on another stream (branch / sub-batch streams): order behind that kernel
         return ent[2]
     wt = ops.transpose2d(w.detach())
-    w._mm_wt = (w.data_ptr(), w._version, wt)
+    w._mm_wt = (w.data_ptr(), w._version, wt, _streams.stamp(w.device) if w.is_cuda else None)
     return wt
 
 
@@ -226,6 +228,29 @@ def layer_norm(x, w, b, eps):
     return LayerNormFn.apply(x, w, b, eps)
 
 
+class FinalLayerNormSbFn(torch.autograd.Function):
+    """NormPipe (transformer.py:828-839) fused with _post_transformer_block's transpose(0, 1).contiguous()
+    (gpt2_model.py:80-85): x [s, b, h] -> LayerNorm(x) as [b, s, h]; neither direction copies the activation."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        y, mean, rstd = ops.layernorm_fwd_sb(x, w, b, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, grads = ops.layernorm_bwd_sb(dy, x, w, mean, rstd, param_grads=need_p)
+        dw, db = (grads[0], grads[1]) if need_p else (None, None)
+        return dx, dw, db, None
+
+
+def final_layer_norm_sb(x, w, b, eps):
+    return FinalLayerNormSbFn.apply(x.contiguous(), w, b, eps)
+
+
 class DualLayerNormFn(torch.autograd.Function):
     """(LN(x; w1, b1), LN(x; w2, b2)) from one read of x and shared statistics: the GPT-J residual variant
     normalises the same input twice (megatron/model/transformer.py:737)."""
@@ -375,7 +400,7 @@ class BiasDropoutAddFn(torch.autograd.Function):
         dx = g
         if ctx.drop:
             (keep,) = ctx.saved_tensors
-            dx = (g * keep.to(g.dtype)) * (1.0 / (1.0 - ctx.p))  # rare path (every listed config has p = 0)
+            dx = ops.dropout_bwd(g, keep, ctx.p)
         db = ops.colsum(_flat2d(dx)) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         dres = g if (ctx.has_res and ctx.needs_input_grad[2]) else None
         return dx, db, dres, None, None, None, None, None
@@ -441,27 +466,31 @@ class LmHeadLossFn(torch.autograd.Function):
     backward feeds that buffer to the data- / weight-gradient GEMMs and scales their [T, h] / [V, h] results by the loss's
     upstream gradient (a device scalar: no host sync, graph-capturable).  Same loss bits as `linear` +
     `masked_cross_entropy` up to the last place of logsumexp; bf16 only - with fp16 the unscaled gradient would lose what
-    the reference's loss scaling protects - and tensor-parallel size 1 (the vocab-parallel loss needs its three exchanges)."""
+    the reference's loss scaling protects - and tensor-parallel size 1 (the vocab-parallel loss needs its three exchanges).
+    The mask sum, the per-row weights and the final masked mean are two one-block HIP launches (ops.loss_mask_weights /
+    ops.masked_mean): no framework kernel runs in this node."""
 
     @staticmethod
     def forward(ctx, x, weight, labels, loss_mask):
         x2 = _flat2d(x)
         logits = ops.gemm_nt(x2, weight, None, _lib.EPI_NONE)
-        lm = loss_mask.reshape(-1).float()
-        den = lm.sum()
-        losses, _ = ops.cross_entropy_fwd_grad(logits, labels.reshape(-1).contiguous(), (1.0 / den) * lm)
+        row_w, den, lm = ops.loss_mask_weights(loss_mask)
+        losses, _ = ops.cross_entropy_fwd_grad(logits, labels.reshape(-1).contiguous(), row_w)
         ctx.save_for_backward(x2, weight, logits)  # `logits` now holds the gradient for an upstream gradient of 1
         ctx.xshape = x.shape
-        return torch.sum(losses * lm) / den
+        return ops.masked_mean(losses, lm, den)
 
     @staticmethod
     def backward(ctx, gup):
         x2, weight, g = ctx.saved_tensors
+        gup = gup.reshape(1).float()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = (ops.gemm_nt(g, weight_t(weight)) * gup).view(ctx.xshape)
+            dx = ops.gemm_nt(g, weight_t(weight))
+            dx = ops.scale_dev(dx, gup, out=dx).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(g, x2) * gup
+            dw = _wgrad(g, x2)
+            dw = ops.scale_dev(dw, gup, out=dw)
         return dx, dw, None, None
 
 
@@ -472,6 +501,87 @@ def lm_head_loss_supported(x, weight):
 def lm_head_loss(x, weight, labels, loss_mask):
     """x [b, s, h] (after the final norm), weight [V, h], labels / loss_mask [b, s] -> scalar loss."""
     return LmHeadLossFn.apply(x, weight, labels, loss_mask)
+
+
+class FinalNormHeadLossFn(torch.autograd.Function):
+    """_post_transformer_block's transpose (gpt2_model.py:80-85) + NormPipe (transformer.py:828-839) + the bias-free LM head
+    (transformer.py:816-825) + the masked-mean cross entropy (gpt2_model.py:52-70) as ONE node on the layers' [s, b, h]
+    output.  The LayerNorm reads [s, b, h] by stride and writes [b, s, h] (no transposed copy, forward or backward); the
+    loss's upstream gradient (a device scalar) rides into the LayerNorm backward kernel, which is linear in dy, instead of
+    costing a pass over the [T, h] gradient.  Numerics = LayerNormFn + LmHeadLossFn (same kernels, same roundings)."""
+
+    @staticmethod
+    def forward(ctx, x_sbh, ln_w, ln_b, eps, weight, labels, loss_mask):
+        xn, mean, rstd = ops.layernorm_fwd_sb(x_sbh, ln_w, ln_b, eps)   # [b, s, h]
+        x2 = _flat2d(xn)
+        logits = ops.gemm_nt(x2, weight, None, _lib.EPI_NONE)
+        row_w, den, lm = ops.loss_mask_weights(loss_mask)
+        losses, _ = ops.cross_entropy_fwd_grad(logits, labels.reshape(-1).contiguous(), row_w)
+        ctx.save_for_backward(x_sbh, ln_w, mean, rstd, x2, weight, logits)
+        return ops.masked_mean(losses, lm, den)
+
+    @staticmethod
+    def backward(ctx, gup):
+        x_sbh, ln_w, mean, rstd, x2, weight, g = ctx.saved_tensors
+        gup = gup.reshape(1).float()
+        dx = dlw = dlb = dw = None
+        need_ln_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[0] or need_ln_p:
+            dxn = ops.gemm_nt(g, weight_t(weight))  # [T, h] in [b, s] row order, unscaled
+            dx, grads = ops.layernorm_bwd_sb(dxn, x_sbh, ln_w, mean, rstd, dy_scale=gup, param_grads=need_ln_p)
+            if need_ln_p:
+                dlw, dlb = grads
+        if ctx.needs_input_grad[4]:
+            dw = _wgrad(g, x2)
+            dw = ops.scale_dev(dw, gup, out=dw)
+        return dx, dlw, dlb, None, dw, None, None
+
+
+def final_norm_head_loss(x_sbh, ln_w, ln_b, eps, weight, labels, loss_mask):
+    """x_sbh: the last layer's [s, b, h] output; labels / loss_mask [b, s] -> scalar loss."""
+    return FinalNormHeadLossFn.apply(x_sbh, ln_w, ln_b, eps, weight, labels, loss_mask)
+
+
+class ImagePrefixTailFn(torch.autograd.Function):
+    """ImagePrefix.forward behind its encoder (image_prefix.py:232-252): LayerNorm(dropout(x proj^T + b)) for the few rows of a
+    step in one launch (csrc/prefix.hip); the backward is LayerNorm backward -> dropout backward -> the linear's gradients,
+    all HIP launches."""
+
+    @staticmethod
+    def forward(ctx, x2, w, b, ln_w, ln_b, eps, p, training, rng_state, offset):
+        out, ln_in, keep, mean, rstd = ops.prefix_tail_fwd(x2, w, b, ln_w, ln_b, eps, p, training, rng_state, offset)
+        ctx.save_for_backward(x2, w, ln_w, ln_in, mean, rstd, keep)
+        ctx.p = p
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, ln_w, ln_in, mean, rstd, keep = ctx.saved_tensors
+        need_ln_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        dyl, grads = ops.layernorm_bwd(dy.contiguous(), ln_in, ln_w, mean, rstd, param_grads=need_ln_p)
+        dlw, dlb = (grads[0], grads[1]) if need_ln_p else (None, None)
+        if keep is not None:
+            dyl = ops.dropout_bwd(dyl, keep, ctx.p)
+        dx = ops.gemm_nt(dyl, weight_t(w)) if ctx.needs_input_grad[0] else None
+        dw, db = _wgrad_bias(dyl, x2, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return dx, dw, db, dlw, dlb, None, None, None, None, None
+
+
+def image_prefix_tail(enc_out, w, b, ln_w, ln_b, eps, p=0.0, training=False, rng_state=None, offset=0):
+    """enc_out [b, enc] (pooled encoder output -> one prefix token, image_prefix.py:249-250) or [b, P, enc] -> [b, P, h].
+    rng_state / offset: the rng tracker's device Philox state and this draw's position (mpu/random.py draw_device), needed
+    when training with p > 0.  Row counts beyond the fused kernel's range take the GEMM + dropout + LayerNorm launches."""
+    if enc_out.dim() == 2:
+        enc_out = enc_out.unsqueeze(1)
+    bsz, P, enc = enc_out.shape
+    h = w.size(0)
+    x2 = enc_out.reshape(bsz * P, enc)
+    if ops.prefix_tail_supported(bsz * P, enc, h):
+        return ImagePrefixTailFn.apply(x2, w, b, ln_w, ln_b, float(eps), float(p), bool(training), rng_state, int(offset)).view(bsz, P, h)
+    y = linear(x2, w, b)
+    if training and p > 0:
+        y = bias_dropout_add(y, None, None, p, True, 0, offset, rng_state=rng_state)
+    return layer_norm(y, ln_w, ln_b, eps).view(bsz, P, h)
 
 
 class EmbedPrefixFn(torch.autograd.Function):

@@ -105,12 +105,13 @@ class ImagePrefixProj(nn.Module):
         self.dropout_p = dropout_p
         self.to(dtype)
 
-    def forward(self, enc_out):  # [b, P, enc_dim]
-        y = Fn.linear(enc_out, self.proj.weight, self.proj.bias)
-        if self.training and self.dropout_p > 0:
-            state, pos = mpu.get_cuda_rng_tracker().draw_device(y.device)  # fresh mask at every HIP-graph replay too
-            y = Fn.bias_dropout_add(y, None, None, self.dropout_p, True, 0, pos, rng_state=state)
-        return self.ln(y)
+    def forward(self, enc_out):  # [b, enc_dim] (pooled) or [b, P, enc_dim]
+        state, pos = None, 0
+        drop = self.training and self.dropout_p > 0
+        if drop:
+            state, pos = mpu.get_cuda_rng_tracker().draw_device(enc_out.device)  # fresh mask at every HIP-graph replay too
+        return Fn.image_prefix_tail(enc_out, self.proj.weight, self.proj.bias, self.ln.weight, self.ln.bias, self.ln.eps,
+                                    self.dropout_p, drop, state, pos)
 
 
 class MagmaStack(nn.Module):
@@ -159,8 +160,8 @@ class MagmaStack(nn.Module):
         """(sum of masked token losses, number of unmasked tokens) of one (sub-)batch: final LayerNorm, LM head
         (transformer.py:816-839) and the vocabulary-parallel loss over the TP group (gpt2_model.py:52-70 ->
         mpu/cross_entropy.py:27-117: three [b, s] exchanges; each rank's softmax covers its own vocabulary partition)."""
-        x = self.final_norm(x.transpose(0, 1).contiguous())
-        logits, _ = self.final_linear(x)  # [b, s, V/p]: gather_output=False (transformer.py:151-161)
+        xn = Fn.final_layer_norm_sb(x, self.final_norm.weight, self.final_norm.bias, self.final_norm.eps)  # [b, s, h], no copy
+        logits, _ = self.final_linear(xn)  # [b, s, V/p]: gather_output=False (transformer.py:151-161)
         losses = mpu.vocab_parallel_cross_entropy(logits, labels)
         lm = loss_mask.reshape(-1).float()
         return torch.sum(losses.reshape(-1) * lm), lm.sum()
@@ -177,7 +178,7 @@ class MagmaStack(nn.Module):
         recompute = self.cfg.get("checkpoint_activations", False)
         if tp > 1 and chunks > 1 and b % chunks == 0 and not recompute:
             # tensor parallel: sub-batches walk the layers in lock step on separate streams, so that each sub-batch's
-            # all-reduces overlap the other's GEMMs / attention (mpu/overlap.py); bit-identical to the unsplit run
+            # all-reduces overlap the other's GEMMs / attention (mpu/overlap.py); same activations as the unsplit run
             xs = mpu.split_batch(x, chunks, dim=1)
             lbl, lms = torch.chunk(labels, chunks, dim=0), torch.chunk(loss_mask, chunks, dim=0)
             stages = [(lambda t, layer=layer: layer(t, mask)) for layer in self.layers]
@@ -193,12 +194,13 @@ class MagmaStack(nn.Module):
         if tp > 1:
             total, count = self._head_loss_parts(x, labels, loss_mask)
             return total / count
-        x = x.transpose(0, 1).contiguous()
-        x = self.final_norm(x)
         w = self.final_linear.weight
+        fn = self.final_norm
         if self.cfg.get("fused_head_loss", True) and torch.is_grad_enabled() and Fn.lm_head_loss_supported(x, w):
-            return Fn.lm_head_loss(x, w, labels, loss_mask)  # head + loss, logits read once
-        logits, _ = self.final_linear(x)
+            # transpose + final norm + head + loss as one node, logits read once, no [b, s, h] copy
+            return Fn.final_norm_head_loss(x, fn.weight, fn.bias, fn.eps, w, labels, loss_mask)
+        xn = Fn.final_layer_norm_sb(x, fn.weight, fn.bias, fn.eps)
+        logits, _ = self.final_linear(xn)
         return Fn.masked_cross_entropy(logits, labels, loss_mask)
 
 

@@ -77,10 +77,9 @@ def fused_kernel_eligible(fusion_type, sixteen_bit, has_mask, b, np, sq, sk):
 
 
 class FusedScaleMaskSoftmax(nn.Module):
-    """Constructor and methods as the reference's (fused_softmax.py:92-205).  Shapes or dtypes the kernels do not take run
-    the reference's own eager sequence (`forward_torch_softmax`, in-place masked_fill through `mask_func`): that branch is
-    reference behaviour, not a stand-in for a missing library - constructing the module with a fusion type loads
-    libmm_hip.so and raises if it is absent."""
+    """Constructor and methods as the reference's (fused_softmax.py:92-205).  Shapes the reference's eligibility rule sends
+    to its eager sequence (`forward_torch_softmax`) run on the HIP masked kernel too; what that kernel cannot take raises -
+    the module computes nothing outside libmm_hip.so."""
 
     def __init__(self, input_in_fp16, input_in_bf16, fusion_type, mask_func, softmax_in_fp32, scale):
         super().__init__()
@@ -119,15 +118,22 @@ class FusedScaleMaskSoftmax(nn.Module):
         return ScaledMaskedSoftmax.apply(input, mask, scale)
 
     def forward_torch_softmax(self, input, mask):
-        """fused_softmax.py:184-199: optional fp32 up-cast, scale, mask_func (in place), Softmax, cast back."""
-        upcast = self.input_in_float16 and self.softmax_in_fp32
-        x = input.float() if upcast else input
-        if self.scale is not None:
-            x = x * self.scale
-        if mask is not None:
-            x = self.mask_func(x, mask)
-        probs = torch.softmax(x, dim=-1)
-        return probs.to(torch.float16 if self.input_in_fp16 else torch.bfloat16) if upcast else probs
+        """The reference's eager branch (fused_softmax.py:184-199: optional fp32 up-cast, scale, `mask_func` = fill with
+        -10000, Softmax(dim=-1), cast back) for shapes its fused-kernel rule rejects.  Here it runs on the SAME HIP masked
+        kernel, which has no divisibility requirement of its own: fp32 statistics on the 16-bit scores, scale applied
+        before the -10000 fill - the eager sequence's arithmetic with softmax_in_fp32 (and what a GPU's 16-bit softmax
+        computes internally without it).  Nothing in this package computes outside libmm_hip.so: inputs the kernel cannot
+        take (fp32 scores, more than 2048 keys, a single query row - the kv-cache decode shape, out of scope) raise.
+        Unlike the reference's in-place masked_fill_ the scores tensor is left untouched."""
+        b, np, sq, sk = input.size()
+        if not self.input_in_float16 or input.dtype not in (torch.float16, torch.bfloat16):
+            raise RuntimeError("FusedScaleMaskSoftmax: only 16-bit attention scores are on the HIP path (no eager fallback)")
+        if sk > MAX_FUSED_KEYS or sq < 2:
+            raise RuntimeError(f"FusedScaleMaskSoftmax: [sq={sq}, sk={sk}] is outside the HIP softmax kernel's range "
+                               f"(2 <= sq, sk <= {MAX_FUSED_KEYS}); there is no eager fallback")
+        if mask is None:
+            mask = torch.zeros(1, 1, sq, sk, dtype=torch.uint8, device=input.device)  # nothing masked
+        return ScaledMaskedSoftmax.apply(input, mask, 1.0 if self.scale is None else self.scale)
 
     @staticmethod
     def get_batch_per_block(sq, sk, b, np):

@@ -3,6 +3,8 @@ own arithmetic - including its quirk that, once the engine has cast the module, 
 the module dtype (bf16 positions above 256 are rounded) - and handed to the HIP kernel as an input."""
 import torch
 
+from .. import _streams
+
 
 class RotaryEmbedding(torch.nn.Module):
     def __init__(self, dim, base=10000, precision=torch.half):
@@ -14,6 +16,7 @@ class RotaryEmbedding(torch.nn.Module):
         self.cos_cached = None
         self.sin_cached = None
         self.precision = precision
+        self._stamp = None  # event behind the kernels that filled the cache (multimodal_amd/_streams.py)
 
     def forward(self, x, seq_dim=1, seq_len=None):
         """Returns (cos, sin) as [seq_len, 1, 1, dim] like the reference."""
@@ -31,6 +34,9 @@ class RotaryEmbedding(torch.nn.Module):
             if self.precision == torch.bfloat16:
                 self.cos_cached = self.cos_cached.bfloat16()
                 self.sin_cached = self.sin_cached.bfloat16()
+            self._stamp = _streams.stamp(x.device) if x.is_cuda else None
+        elif self._stamp is not None:
+            _streams.wait(self._stamp, x.device)
         return self.cos_cached, self.sin_cached
 
     def tables(self, x, seq_len):

@@ -8,9 +8,13 @@ all-reduce -> LayerNorm -> ...) nothing can run beside it.  So the micro-batch i
 walk the layers in lock step on separate HIP streams: while sub-batch 0 waits for its all-reduce, sub-batch 1's GEMMs and
 attention run.  RCCL executes the collectives on its own stream in issue order (the same order on every rank: same program),
 each compute stream waits only for its own collective.  Every op of the layer is independent across b (attention works per
-(batch element, head); LayerNorm, GEMMs and the elementwise kernels per token row), so the result is bit-identical to the
-unsplit run - tests/test_mpu_cpu.py (gloo, CPU) and tests/test_tp2_gpu.py check exactly that.  The collectives stay outside
-any HIP-graph capture.
+(batch element, head); LayerNorm, GEMMs and the elementwise kernels per token row), so activations and input gradients equal
+the unsplit run's; a WEIGHT gradient is the sum of the sub-batches' contributions, accumulated by autograd in the parameter's
+16-bit dtype, i.e. summed in a different order than the unsplit run's single GEMM (tests/test_tp2_gpu.py allows 2^-6 of the
+largest value there; tests/test_mpu_cpu.py checks the schedule over gloo).  The collectives stay outside any HIP-graph capture.
+Lazily built device caches shared by the sub-batches (transposed frozen weights, rotary tables, the rng tracker's device
+state) carry an event of the stream that filled them and every other stream waits for it (multimodal_amd/_streams.py):
+the sub-batch streams are otherwise only ordered at entry and exit.
 """
 import torch
 

@@ -26,6 +26,7 @@ class RngStatesTracker:
         self.active_ = "default"
         self.states_["default"] = [0, 0]
         self.dev_ = {}      # (name, device) -> uint64[2] device tensor {seed, base offset} (stored as int64)
+        self.dev_stamp_ = {}  # (name, device) -> event behind the upload that created it (multimodal_amd/_streams.py)
         self.pending_ = {}  # (name, device) -> draws since the last commit (host side: positions inside the step)
 
     def add(self, name, seed):
@@ -62,11 +63,15 @@ class RngStatesTracker:
         """(state tensor, offset within the step) for the next dropout launch on the active stream: the kernel draws from
         (state[0], state[1] + offset).  The device state is created on first use from the stream's host (seed, offset)."""
         import torch
+        from .. import _streams
         key = (self.active_, torch.device(device))
         st = self.dev_.get(key)
         if st is None:
             seed, off = self.states_[self.active_]
             st = self.dev_[key] = torch.tensor([seed, off], dtype=torch.int64, device=device)
+            self.dev_stamp_[key] = _streams.stamp(device) if st.is_cuda else None
+        else:
+            _streams.wait(self.dev_stamp_.get(key), device)  # created on another stream (mpu/overlap.py sub-batches)
         pos = self.pending_.get(key, 0)  # (absent after set_states() of a snapshot taken before the stream's first draw)
         self.pending_[key] = pos + n
         return st, pos

@@ -121,15 +121,55 @@ def layernorm_bwd(dy, x, w, mean, rstd, dy2=None, w2=None, dresidual=None, param
     check(lib.mm_layernorm_bwd(dx.data_ptr(), _ptr(partial), dy.data_ptr(), _ptr(dy2), _ptr(dres), x2.data_ptr(),
                                w.data_ptr(), _ptr(w2), mean.data_ptr(), rstd.data_ptr(), rows, h, dtype_code(x.dtype),
                                _stream()), "layernorm_bwd")
+    grads = _ln_finalize(partial, nblk, nvec, h, x) if param_grads else None
+    return dx.view(x.shape), grads
+
+
+def layernorm_fwd_sb(x, w, b, eps):
+    """Final LayerNorm fused with the [s, b, h] -> [b, s, h] transpose (mm_layernorm_fwd_sb): x [s, b, h] contiguous ->
+    (y [b, s, h], mean [b*s], rstd [b*s])."""
+    _need_cuda(x, w, b)
+    if x.dim() != 3 or not x.is_contiguous():
+        raise RuntimeError("layernorm_fwd_sb: x must be a contiguous [s, b, h] tensor")
+    s, bsz, h = x.shape
+    y = torch.empty(bsz, s, h, dtype=x.dtype, device=x.device)
+    mean = torch.empty(s * bsz, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(s * bsz, dtype=torch.float32, device=x.device)
+    check(get_lib().mm_layernorm_fwd_sb(y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                        s, bsz, h, float(eps), dtype_code(x.dtype), _stream()), "layernorm_fwd_sb")
+    return y, mean, rstd
+
+
+def layernorm_bwd_sb(dy, x, w, mean, rstd, dy_scale=None, param_grads=True):
+    """dy [b, s, h] (optionally times the device fp32 scalar dy_scale), x [s, b, h] -> (dx [s, b, h], [dw, db] | None)."""
+    _need_cuda(dy, x, w, dy_scale)
+    s, bsz, h = x.shape
+    dy = dy.contiguous()
+    if dy.numel() != x.numel() or not x.is_contiguous():
+        raise RuntimeError("layernorm_bwd_sb: dy [b, s, h] and a contiguous x [s, b, h] of the same size expected")
+    if dy_scale is not None and (dy_scale.dtype != torch.float32 or dy_scale.numel() != 1):
+        raise RuntimeError("layernorm_bwd_sb: dy_scale must be a one-element fp32 device tensor")
+    dx = torch.empty_like(x)
+    lib = get_lib()
+    partial, nblk = None, 0
+    if param_grads:
+        nblk = lib.mm_layernorm_bwd_nblk(s * bsz)
+        partial = torch.empty(nblk * 2 * h, dtype=torch.float32, device=x.device)
+    check(lib.mm_layernorm_bwd_sb(dx.data_ptr(), _ptr(partial), dy.data_ptr(), _ptr(dy_scale), x.data_ptr(), w.data_ptr(),
+                                  mean.data_ptr(), rstd.data_ptr(), s, bsz, h, dtype_code(x.dtype), _stream()), "layernorm_bwd_sb")
     grads = None
     if param_grads:
-        import ctypes
-        outs = [torch.empty(h, dtype=x.dtype, device=x.device) for _ in range(nvec)]
-        arr = (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs] + [None] * (4 - nvec))
-        check(lib.mm_layernorm_bwd_finalize(ctypes.cast(arr, ctypes.c_void_p), partial.data_ptr(), nblk, nvec, h,
-                                            dtype_code(x.dtype), _stream()), "layernorm_bwd_finalize")
-        grads = outs
-    return dx.view(x.shape), grads
+        grads = _ln_finalize(partial, nblk, 2, h, x)
+    return dx, grads
+
+
+def _ln_finalize(partial, nblk, nvec, h, like):
+    import ctypes
+    outs = [torch.empty(h, dtype=like.dtype, device=like.device) for _ in range(nvec)]
+    arr = (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs] + [None] * (4 - nvec))
+    check(get_lib().mm_layernorm_bwd_finalize(ctypes.cast(arr, ctypes.c_void_p), partial.data_ptr(), nblk, nvec, h,
+                                              dtype_code(like.dtype), _stream()), "layernorm_bwd_finalize")
+    return outs
 
 
 # ---------------------------------------------------------------------------- rotary / gelu / bias-dropout-add
@@ -535,7 +575,79 @@ def cross_entropy_fwd_grad(logits, labels, row_weight):
     return loss, lse
 
 
+def loss_mask_weights(loss_mask):
+    """fp32 [T] loss mask -> (row_weight = mask / sum(mask) [T], den = sum(mask) [1]), one launch (gpt2_model.py:64-70)."""
+    _need_cuda(loss_mask)
+    lm = loss_mask.reshape(-1)
+    lm = lm if lm.dtype == torch.float32 else lm.float()
+    lm = lm.contiguous()
+    w = torch.empty_like(lm)
+    den = torch.empty(1, dtype=torch.float32, device=lm.device)
+    check(get_lib().mm_loss_mask_weights(w.data_ptr(), den.data_ptr(), lm.data_ptr(), lm.numel(), _stream()), "loss_mask_weights")
+    return w, den, lm
+
+
+def masked_mean(losses, lm, den):
+    """sum(losses * lm) / den as a 0-dim fp32 tensor, one launch."""
+    _need_cuda(losses, lm, den)
+    out = torch.empty((), dtype=torch.float32, device=losses.device)
+    check(get_lib().mm_masked_mean(out.data_ptr(), losses.data_ptr(), lm.data_ptr(), den.data_ptr(), losses.numel(), _stream()),
+          "masked_mean")
+    return out
+
+
+def scale_dev(x, scalar, out=None):
+    """x * scalar with `scalar` a one-element fp32 DEVICE tensor (no host sync); 16-bit x, numel % 8 == 0."""
+    _need_cuda(x, scalar)
+    x = x.contiguous()
+    if scalar.dtype != torch.float32 or scalar.numel() != 1:
+        raise RuntimeError("scale_dev: scalar must be a one-element fp32 device tensor")
+    out = torch.empty_like(x) if out is None else out
+    check(get_lib().mm_scale_dev(out.data_ptr(), x.data_ptr(), scalar.data_ptr(), x.numel(), dtype_code(x.dtype), _stream()),
+          "scale_dev")
+    return out
+
+
 # ---------------------------------------------------------------------------- embedding + image prefix
+def prefix_tail_supported(rows, enc_dim, out_dim):
+    return bool(get_lib().mm_prefix_tail_supported(rows, enc_dim, out_dim))
+
+
+def prefix_tail_fwd(x, w, bias, ln_w, ln_b, eps, p=0.0, training=False, rng_state=None, offset=0):
+    """LayerNorm(dropout(x W^T + bias)) in one launch (mm_prefix_tail_fwd).  x [rows, enc]; returns
+    (out [rows, h], ln_in [rows, h], keep uint8 [rows, h] | None, mean [rows], rstd [rows])."""
+    _need_cuda(x, w, bias, ln_w, ln_b, rng_state)
+    x = x.contiguous()
+    rows, enc = x.shape
+    h = w.size(0)
+    lib = get_lib()
+    drop = bool(training) and p > 0
+    if drop and (rng_state is None or rng_state.dtype != torch.int64 or rng_state.numel() != 2):
+        raise RuntimeError("prefix_tail_fwd: training with p > 0 needs rng_state, a device int64[2] tensor {seed, base offset}")
+    out = torch.empty(rows, h, dtype=x.dtype, device=x.device)
+    ln_in = torch.empty(rows, h, dtype=x.dtype, device=x.device)
+    keep = torch.empty(rows, h, dtype=torch.uint8, device=x.device) if drop else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.mm_prefix_tail_workspace_bytes(rows, h), dtype=torch.uint8, device=x.device)
+    check(lib.mm_prefix_tail_fwd(out.data_ptr(), ln_in.data_ptr(), _ptr(keep), mean.data_ptr(), rstd.data_ptr(), x.data_ptr(),
+                                 w.contiguous().data_ptr(), _ptr(bias), ln_w.data_ptr(), ln_b.data_ptr(), ws.data_ptr(), rows, enc, h,
+                                 float(eps), float(p), int(bool(training)), _ptr(rng_state), int(offset), dtype_code(x.dtype),
+                                 _stream()), "prefix_tail_fwd")
+    return out, ln_in, keep, mean, rstd
+
+
+def dropout_bwd(g, keep, p):
+    """keep ? g / (1 - p) : 0."""
+    _need_cuda(g, keep)
+    g = g.contiguous()
+    dx = torch.empty_like(g)
+    check(get_lib().mm_dropout_bwd(dx.data_ptr(), g.data_ptr(), keep.data_ptr(), g.numel(), float(p), dtype_code(g.dtype), _stream()),
+          "dropout_bwd")
+    return dx
+
+
+
 def embed_prefix(table, tokens, prefix=None):
     """[s, b, h] input of the first layer: out[si, bi] = prefix[bi, si] for si < P else table[tokens[bi, si - P]]
     (word-embedding gather + image-prefix concat + [b,s,h]->[s,b,h] transpose in one kernel)."""

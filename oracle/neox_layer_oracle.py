@@ -408,3 +408,25 @@ def vocab_parallel_cross_entropy(logit_shards, target):
         predicted = predicted + pr.masked_fill(outside, 0.0)
         sum_exp = sum_exp + torch.exp(sh).sum(dim=-1)
     return torch.log(sum_exp) - predicted
+
+
+# --------------------------------------------------------------------------------- image prefix + embedding (row f3)
+def image_prefix_tail(enc_out, proj_w, proj_b, ln_w, ln_b, eps=1e-5, dropout_p=0.0, training=False):
+    """ImagePrefix.forward behind its encoder (megatron/model/image_prefix.py:224-252): `enc_out` is the encoder's output,
+    [b, enc] (pooled: openclip-H as coded, :106) or [b, P, enc]; proj (:232) -> dropout (:243) -> LayerNorm (:245-246) ->
+    unsqueeze(1) for the 2-D case (:249-250).  Returns [b, P, h]."""
+    y = F.linear(enc_out, proj_w, proj_b)
+    y = F.dropout(y, p=dropout_p, training=training)
+    y = F.layer_norm(y, (y.size(-1),), ln_w, ln_b, eps)
+    return y.unsqueeze(1) if y.dim() == 2 else y
+
+
+def embed_with_prefix(prefix, table, tokens):
+    """EmbeddingPipe.forward (megatron/model/word_embeddings.py:182-205: word embeddings, rotary => no position embedding
+    :138-149, embedding dropout 0) + cat((image_embeddings, word_embeddings[:, :-P]), dim=1) (:197-203), then
+    _pre_transformer_block's [b, s, h] -> [s, b, h] (megatron/model/gpt2_model.py:73-77).  prefix: [b, P, h] or None."""
+    emb = F.embedding(tokens, table)
+    if prefix is not None:
+        emb = torch.cat((prefix, emb[:, : -prefix.shape[1], :]), dim=1)
+    return emb.transpose(0, 1).contiguous()
+

@@ -76,6 +76,7 @@ def install_torchtyping_stub():
             return torch.Tensor
 
     tt.TensorType = TensorType
+    tt.patch_typeguard = lambda: None  # imported by image_prefix.py:3, its call at :16 is commented out
     sys.modules["torchtyping"] = tt
 
 
@@ -264,6 +265,78 @@ def run_ce_case(c, tp, rank):
     _io.save(name, dict(logits=logits, labels=labels, gout=gout, loss=loss.detach(), dlogits=mine32.grad, dlogits16=mine16.grad),
              dict(b=b, s=s, V=V, tp=tp, rank=rank, seed=c["seed"], source="megatron/mpu/cross_entropy.py:27-117 run on CPU (gloo)"))
     print("wrote", name, "loss[0,:3]=", loss.detach()[0, :3].tolist())
+
+
+# ------------------------------------------------------------------- image prefix tail + embedding concat
+def install_encoder_stubs():
+    """megatron/model/image_prefix.py:7-8 imports timm and open_clip at module level for its encoder FACTORIES
+    (image_prefix.py:32-149), which need network weights and are out of scope; the tail that is pinned here
+    (proj -> dropout -> LayerNorm -> unsqueeze, :217-252) never calls them.  Import-only stubs, no arithmetic."""
+    for name in ("timm", "open_clip"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+
+
+EMBED_CASES = [dict(b=3, s=24, V=96, h=256, enc=64, ndim=2, seed=8100),    # pooled encoder output [b, enc] -> 1 prefix token (openclip-H as coded)
+               dict(b=2, s=24, V=96, h=256, enc=64, ndim=3, P=5, seed=8101),  # un-pooled [b, P, enc] -> P prefix tokens
+               dict(b=4, s=40, V=128, h=1024, enc=1024, ndim=2, seed=8102)]   # the 410M widths (proj 1024 -> 1024)
+
+
+def run_embed_case(c, dt):
+    """The reference's own ImagePrefix.forward (encoder replaced by the identity: its pooled output is the INPUT) and
+    EmbeddingPipe.forward (megatron/model/word_embeddings.py:182-205) followed by _pre_transformer_block
+    (megatron/model/gpt2_model.py:73-77), eval mode (dropout is the identity; its training-mode mask comes from the device
+    generator and cannot be pinned), backward through the prefix only (frozen word embeddings, training.py:454-459)."""
+    from megatron import mpu
+    from megatron.model import image_prefix as IP
+    from megatron.model import word_embeddings as WE
+    rng = np.random.default_rng(c["seed"])
+    b, s, V, h, enc = c["b"], c["s"], c["V"], c["h"], c["enc"]
+    pre = object.__new__(IP.ImagePrefix)        # __init__ builds the CLIP encoder (network weights): set the tail's attributes
+    torch.nn.Module.__init__(pre)
+    pre.encoder_type = "openclip-H"             # in ENCODER_SEQ_LENS: no rearrange (image_prefix.py:235-240)
+    pre.enc = torch.nn.Identity()
+    pre.out_dim = h
+    pre.proj = torch.nn.Linear(enc, h)
+    pre.dropout = torch.nn.Dropout(0.1)
+    pre.use_layernorm = True
+    pre.ln = torch.nn.LayerNorm(h)
+    with torch.no_grad():
+        pre.proj.weight.copy_(rng_t(rng, (h, enc), enc ** -0.5))
+        pre.proj.bias.copy_(rng_t(rng, (h,), 0.1))
+        pre.ln.weight.copy_(rng_t(rng, (h,), 0.1, 1.0))
+        pre.ln.bias.copy_(rng_t(rng, (h,), 0.1))
+    args = make_args(h, 2, 2, s, dt, 1.0, False, False, 1)
+    emb = object.__new__(WE.EmbeddingPipe)      # Embedding.__init__ is fine, EmbeddingPipe.__init__ would build the encoder
+    WE.Embedding.__init__(emb, SimpleNamespace(**vars(args), mup_embedding_mult=1.0, mup_rp_embedding_mult=1.0,
+                                               use_bnb_optimizer=False, opt_pos_emb_offset=0),
+                          h, V, s, 0.0, torch.nn.init.zeros_, 0, True)
+    emb.image_prefix = pre
+    table = rng_t(rng, (V, h), 0.05)
+    with torch.no_grad():
+        emb.word_embeddings.weight.copy_(table)
+    emb = emb.to(DT[dt])
+    emb.eval()
+    for nme, p_ in emb.named_parameters():
+        p_.requires_grad = "image_prefix" in nme
+    x_enc = rng_t(rng, (b, enc) if c["ndim"] == 2 else (b, c["P"], enc)).to(DT[dt]).requires_grad_(True)
+    tokens = torch.from_numpy(rng.integers(0, V, (b, s)))
+    pos = torch.arange(s).unsqueeze(0).expand(b, s)
+    out, _ = emb((x_enc, tokens, pos, causal_mask(s)))
+    x0 = out.transpose(0, 1).contiguous()       # gpt2_model.py:73-77
+    prefix = pre(x_enc)
+    g = rng_t(rng, tuple(x0.shape)).to(DT[dt])
+    x0.backward(g)
+    name = "op_embed_prefix_h%d_nd%d_%s" % (h, c["ndim"], dt)
+    _io.save(name, dict(enc=x_enc.detach(), tokens=tokens, table=emb.word_embeddings.weight.detach(),
+                        proj_w=pre.proj.weight.detach(), proj_b=pre.proj.bias.detach(), ln_w=pre.ln.weight.detach(),
+                        ln_b=pre.ln.bias.detach(), prefix=prefix.detach(), x0=x0.detach(), g=g, d_enc=x_enc.grad,
+                        d_proj_w=pre.proj.weight.grad, d_proj_b=pre.proj.bias.grad, d_ln_w=pre.ln.weight.grad,
+                        d_ln_b=pre.ln.bias.grad),
+             dict(b=b, s=s, V=V, h=h, enc=enc, P=int(prefix.shape[1]), seed=c["seed"], dtype=dt, eps=1e-5,
+                  source="megatron/model/image_prefix.py:217-252 + megatron/model/word_embeddings.py:182-205 + "
+                         "megatron/model/gpt2_model.py:73-77 run on CPU (eval mode, encoder = identity)"))
+    print("wrote", name, "x0[0,0,:3]=", x0.detach().float()[0, 0, :3].tolist())
 
 
 # ------------------------------------------------------------------- per-op cases
@@ -484,7 +557,7 @@ def worker_tp(rank, world, port, which):
 
 
 def main():
-    which = sys.argv[1:] or ["ops", "layers", "big", "stack", "tp2", "hn128", "adapters", "ce"]
+    which = sys.argv[1:] or ["ops", "layers", "big", "stack", "tp2", "hn128", "adapters", "ce", "embed"]
     import torch.multiprocessing as mp
     if {"tp2", "hn128", "adapters", "ce"} & set(which):
         mp.spawn(worker_tp, args=(2, 29533, which), nprocs=2, join=True)
@@ -516,6 +589,11 @@ def main():
     if "ce" in which:
         for c in CE_CASES:
             run_ce_case(c, 1, 0)
+    if "embed" in which:
+        install_encoder_stubs()
+        for c in EMBED_CASES:
+            for dt in (("bf16",) if c["h"] >= 1024 else ("f32", "bf16")):  # the wide case: 16-bit only (fixture size)
+                run_embed_case(c, dt)
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ def header_functions():
     src = open(os.path.join(ROOT, "include", "mm_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"(?:int|const char\*)\s+(mm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(?:int|size_t|const char\*)\s+(mm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
     return out

@@ -115,6 +115,53 @@ def test_attention_410m_shape_properties(cuda_device):
     assert torch.isfinite(dqkv.float()).all()
 
 
+@pytest.mark.parametrize("s,b,np_,hn,mode", [(1024, 1, 2, 128, "causal"),      # summit-1-3B / 6-7B head size, 16 key tiles
+                                              (2048, 1, 1, 128, "causal"),      # ... and the full 32 key tiles of s = 2048
+                                              (2048, 1, 1, 128, "general"),     # byte-mask path at the full sequence length
+                                              (2048, 1, 2, 64, "general"),
+                                              (1000, 2, 1, 128, "causal_bytes")])  # ragged last tile, hn = 128
+def test_attention_long_sequence_vs_fp32(cuda_device, s, b, np_, hn, mode):
+    """Head size 128 (configs/summit-1-3B.yml:20-26, 6-7B.yml:9-15) and the byte-mask path at the sequence lengths the configs
+    run: the causal tile skip, the heavy-first grid and the 1-workgroup-per-CU hn = 128 instantiation over 16-32 key tiles,
+    against the fp32 CPU restatement (a few seconds of host time each)."""
+    run_case(cuda_device, "bf16", s, b, np_, hn, mode, seed=7 * s + hn)
+
+
+def test_attention_hn128_s2048_shape_properties(cuda_device):
+    """The summit-1-3B attention shape per TP rank (s=2048, b=4, np=9, hn=128): size-independent properties, as in
+    test_attention_410m_shape_properties, plus the same checks through the byte-mask kernels with the causal mask given as
+    bytes (must equal the implicit-causal result bit for bit, forward and backward)."""
+    from multimodal_amd import ops
+    torch.manual_seed(5)
+    s, b, np_, hn = 2048, 4, 9, 128
+    scale = 1.0 / math.sqrt(hn)
+    qkv = torch.randn(s, b, np_, 3 * hn, device=cuda_device).bfloat16()
+    ctx, lse = ops.attn_fwd(qkv, s, b, np_, hn, scale, None)
+    v = qkv[..., 2 * hn:]
+    assert torch.equal(ctx[0].view(b, np_, hn), v[0]), "query 0 sees only key 0"
+    q2 = qkv.clone()
+    q2[..., 2 * hn:] = 1.0
+    c_const, _ = ops.attn_fwd(q2, s, b, np_, hn, scale, None)
+    assert (c_const.float() - 1.0).abs().max() <= 2 ** -7
+    q3 = qkv.clone()
+    q3[..., 2 * hn:] = v * 2
+    c_dbl, l_dbl = ops.attn_fwd(q3, s, b, np_, hn, scale, None)
+    assert torch.equal(c_dbl.float(), ctx.float() * 2) and torch.equal(l_dbl, lse)
+    dctx = torch.ones(s, b, np_ * hn, device=cuda_device).bfloat16()
+    dqkv = ops.attn_bwd(dctx, ctx, lse, qkv, s, b, np_, hn, scale, None)
+    tot = dqkv[..., 2 * hn:].float().sum(dim=0)
+    assert (tot / s - 1.0).abs().max() <= 2e-2
+    assert torch.isfinite(dqkv.float()).all()
+    mask = torch.triu(torch.ones(s, s, dtype=torch.bool, device=cuda_device), 1).view(1, 1, s, s)
+    c_m, l_m = ops.attn_fwd(qkv, s, b, np_, hn, scale, mask)
+    assert torch.equal(c_m, ctx) and torch.allclose(l_m, lse, atol=1e-6)
+    rnd = torch.randn(s, b, np_ * hn, device=cuda_device).bfloat16()
+    g0 = ops.attn_bwd(rnd, ctx, lse, qkv, s, b, np_, hn, scale, None)
+    g1 = ops.attn_bwd(rnd, ctx, lse, qkv, s, b, np_, hn, scale, mask)
+    rel = float((g0.float() - g1.float()).norm() / g0.float().norm())
+    assert rel <= 2 ** -9, rel  # same arithmetic up to the lse the two forwards returned (equal to 1e-6)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("s,b,np_,hn,d,offset,mode", [(200, 2, 2, 64, 16, 0, "causal"), (128, 1, 3, 64, 64, 3, "causal"),
                                                       (96, 2, 2, 64, 32, 0, "general"), (160, 2, 2, 128, 128, 0, "causal"),

@@ -139,3 +139,39 @@ def test_eligibility_table_matches_the_oracle(cuda_device):
         FusedScaleMaskSoftmax(True, False, SoftmaxFusionTypes.general, _mask_func, False, 0.5)  # scaled softmax must be fp32
     with pytest.raises(AssertionError):
         FusedScaleMaskSoftmax(True, False, "general", _mask_func, False, None)
+
+
+def test_ineligible_shapes_run_on_the_hip_kernel_or_raise(cuda_device):
+    """FusedScaleMaskSoftmax.forward_torch_softmax (the reference's eager branch, fused_softmax.py:184-199) computes on the HIP
+    masked kernel for every 16-bit shape it can take - odd sizes, no mask, fusion type none - and raises for the rest:
+    nothing in the package computes outside libmm_hip.so."""
+    from multimodal_amd.model.fused_softmax import FusedScaleMaskSoftmax, SoftmaxFusionTypes
+    torch.manual_seed(0)
+    for dt in (torch.bfloat16, torch.float16):
+        for (b, np_, sq, sk, scale, in32) in ((1, 3, 5, 19, None, False), (2, 1, 7, 130, 0.5, True), (1, 1, 2, 2048, None, False)):
+            m = FusedScaleMaskSoftmax(dt == torch.float16, dt == torch.bfloat16, SoftmaxFusionTypes.none, _mask_func, in32, scale)
+            x = (torch.randn(b, np_, sq, sk) * 3).to(dt)
+            mask = torch.rand(b, 1, sq, sk) < 0.3
+            for mk in (mask, None):
+                xin = x.to(cuda_device).clone().requires_grad_(True)
+                before = xin.detach().clone()
+                p = m(xin, mk.to(cuda_device) if mk is not None else None)
+                assert torch.equal(xin.detach(), before), "scores are not modified"
+                ref = O.softmax_eager(x.clone(), mk, scale, in32)
+                assert (p.detach().float().cpu() - ref.float()).abs().mean() <= 1e-3
+                g = torch.randn(b, np_, sq, sk).to(dt)
+                p.backward(g.to(cuda_device))
+                x32 = x.float().requires_grad_(True)
+                z = x32 * (1.0 if scale is None else scale)
+                if mk is not None:
+                    z = z.masked_fill(mk, -10000.0)
+                torch.softmax(z, -1).backward(g.float())
+                assert (xin.grad.float().cpu() - x32.grad).abs().mean() <= 2e-3
+    m = FusedScaleMaskSoftmax(True, False, SoftmaxFusionTypes.none, _mask_func, False, None)
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 1, 4, 4100, device=cuda_device).half(), None)      # more keys than a row kernel holds
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 1, 1, 64, device=cuda_device).half(), None)        # single query row (kv-cache decode)
+    m32 = FusedScaleMaskSoftmax(False, False, SoftmaxFusionTypes.none, _mask_func, False, None)
+    with pytest.raises(RuntimeError):
+        m32(torch.randn(1, 1, 4, 64, device=cuda_device), None)             # fp32 scores

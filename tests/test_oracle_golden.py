@@ -293,3 +293,24 @@ def test_stack_loss_curve_matches_reference(dt):
     tol = 2e-4 if dt == "f32" else 3e-2
     assert max(abs(a - b) for a, b in zip(losses, ref)) <= tol, (losses, ref)
     assert losses[-1] < losses[0] * 0.2  # and it trains (the reference's own bar: loss goes down)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(golden_io.HERE, "op_embed_prefix_*.npz"))))
+def test_image_prefix_and_embedding_match_reference(name):
+    """the reference's ImagePrefix tail (image_prefix.py:217-252, encoder = identity) and
+    EmbeddingPipe.forward + _pre_transformer_block (word_embeddings.py:182-205, gpt2_model.py:73-77), forward bit-exact,
+    gradients of the prefix parameters and of the encoder output to round-off."""
+    t, meta = golden_io.load(name)
+    leaf = {k: t[k].clone().requires_grad_(True) for k in ("enc", "proj_w", "proj_b", "ln_w", "ln_b")}
+    prefix = O.image_prefix_tail(leaf["enc"], leaf["proj_w"], leaf["proj_b"], leaf["ln_w"], leaf["ln_b"], meta["eps"])
+    assert prefix.shape == (meta["b"], meta["P"], meta["h"])
+    assert torch.equal(prefix.detach(), t["prefix"])
+    x0 = O.embed_with_prefix(prefix, t["table"], t["tokens"])
+    assert x0.shape == (meta["s"], meta["b"], meta["h"]) and torch.equal(x0.detach(), t["x0"])
+    x0.backward(t["g"])
+    tol = 1e-5 if meta["dtype"] == "f32" else 2.0 ** -7
+    for k, gk in (("enc", "d_enc"), ("proj_w", "d_proj_w"), ("proj_b", "d_proj_b"), ("ln_w", "d_ln_w"), ("ln_b", "d_ln_b")):
+        ref = t[gk].float()
+        err = (leaf[k].grad.float() - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), (k, err)
+
