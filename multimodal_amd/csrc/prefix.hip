@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256) void prefix_proj_ln_k(u16* __restrict__ out, u
     }
 }
 
+// Zeroes the ticket words in front of a launch.  A kernel, not hipMemsetAsync: under the framework's stream capture on this
+// ROCm the memset ran at capture time instead of becoming a graph node, so a replayed step found the ticket already spent and
+// no workgroup normalised the rows (the replay returned the previous batch's prefix: tools/dev/dbg_prefix_graph.py).
+__global__ void zero_words_k(unsigned* __restrict__ p) { p[threadIdx.x] = 0u; }
+
 // dx = keep ? rnd(g / (1 - p)) : 0 - backward of the dropout above (and of bias_dropout_add's), 8 elements per lane
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_bwd_k(u16* __restrict__ dx, const u16* __restrict__ g, const uint8_t* __restrict__ keep,
@@ -216,12 +221,9 @@ extern "C" int mm_prefix_tail_fwd(void* out, void* ln_in, uint8_t* keep_mask, fl
     if (drop) MM_CHECK_ARG(rng_state != nullptr, "mm_prefix_tail_fwd: training with p > 0 needs rng_state (device uint64[2] {seed, offset})");
     hipStream_t st = (hipStream_t)stream;
     // the ticket counter lives in the first 256 bytes of the workspace and is zeroed on the stream before every launch
-    // (a memset node under graph capture)
-    if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) {
-        set_error("mm_prefix_tail_fwd: hipMemsetAsync failed");
-        return MM_ELAUNCH;
-    }
     unsigned* counter = (unsigned*)workspace;
+    zero_words_k<<<1, 64, 0, st>>>(counter);
+    MM_CHECK_LAUNCH();
     float* ws_y = (float*)((char*)workspace + 256);
     const size_t lds = (size_t)rows * enc_dim * 2 + 16;
     dim3 grid(out_dim / kPrefixColsPerWg), block(256);

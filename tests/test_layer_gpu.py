@@ -218,13 +218,21 @@ def _full_shape_layer_vs_fp32_oracle(cuda_device, h, n, s, b, rotary_pct, gpt_j,
     assert rel(y, y32) <= 8e-3 and rel(dx, xin.grad) <= 8e-3, (rel(y, y32), rel(dx, xin.grad))
     assert float((y.float() - y32).abs().max()) <= 2.0 ** -5 * float(y32.abs().max())
     assert float((dx.float() - xin.grad).abs().max()) <= 2.0 ** -5 * float(xin.grad.abs().max())
-    keys = golden_params.ADAPTER_KEYS if adapter_factor else golden_params.PARAM_ORDER
-    for k in keys:
-        # the name the HIP layer's parameter carries (adapter wrapping renames the LM's: adapter.py:106-107)
-        assert grads[k] is not None, k
-        assert rel(grads[k], p32[k].grad) <= 2e-2, (k, rel(grads[k], p32[k].grad))
     if adapter_factor:
+        for k in golden_params.ADAPTER_KEYS:
+            assert grads[k] is not None, k
+            assert rel(grads[k], p32[k].grad) <= 2e-2, (k, rel(grads[k], p32[k].grad))
         assert all(g is None for k, g in grads.items() if "adapter" not in k)
+        return
+    # Every parameter trainable: a bias / LayerNorm gradient is a sum over T = 8192 tokens of terms of either sign, so its
+    # 16-bit error is set by the cancellation, not by the result's size.  Yardstick: the eager bf16 evaluation
+    # of the same layer - what the reference computes - against the same fp32 oracle; the HIP layer may be 3x as far.
+    p16 = {k: master[k].to(dtype).clone().requires_grad_(True) for k in golden_params.PARAM_ORDER}
+    x16 = x.clone().requires_grad_(True)
+    O.layer_forward(cfg, [p16], x16, O.causal_mask(s)).backward(dy)
+    for k in golden_params.PARAM_ORDER:
+        assert grads[k] is not None, k
+        _check("grad " + k, grads[k], p16[k].grad, p32[k].grad, factor=3.0)
 
 
 def test_full_shape_410m_layer_vs_fp32_oracle(cuda_device):

@@ -187,3 +187,32 @@ def test_fused_final_norm_head_loss_equals_unfused_chain_and_oracle(cuda_device,
     logits32 = (xn32.to(dt).float() @ W.float().cpu().t()).to(dt)  # the reference's bf16 logits, then .float() for the loss
     l_o = O.cross_entropy_loss(logits32, labels.cpu(), lm.cpu())
     assert abs(float(l_f) - float(l_o)) <= 2e-3
+
+
+def test_prefix_tail_replays_correctly_in_a_hip_graph(cuda_device):
+    """The ticket that elects the normalising workgroup must be re-zeroed by a GRAPH NODE: a replayed launch that finds the
+    ticket spent returns the previous batch's rows (seen once with hipMemsetAsync, which ran at capture time)."""
+    from multimodal_amd import ops
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    rows, enc, h = 2, 64, 256
+    w = (torch.randn(h, enc, device=cuda_device) * 0.1).to(dt)
+    b = torch.zeros(h, device=cuda_device, dtype=dt)
+    lw, lb = torch.ones(h, device=cuda_device, dtype=dt), torch.zeros(h, device=cuda_device, dtype=dt)
+    xs = [torch.randn(rows, enc, device=cuda_device).to(dt) for _ in range(3)]
+    eager = [ops.prefix_tail_fwd(x, w, b, lw, lb, 1e-5)[0].clone() for x in xs]
+    static = xs[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.prefix_tail_fwd(static, w, b, lw, lb, 1e-5)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.prefix_tail_fwd(static, w, b, lw, lb, 1e-5)[0]
+    for i, x in enumerate(xs):
+        static.copy_(x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager[i]), f"replay {i}"
