@@ -198,9 +198,20 @@ def main():
         harness.end_of_step()  # device-resident dropout counters move on: a replayed step draws fresh masks
         return loss
 
+    # Eagerly launched steps (every tensor-parallel config, or --no-graph) overlap the data-parallel exchange with the backward:
+    # a bucket's all-reduce starts on a communication stream as soon as its last gradient exists (DeepSpeed's overlap_comm,
+    # configs/magma_pythia_410M.yml:39-48).  A graph-replayed step runs no Python during its backward, so its exchange
+    # (27 MB at this recipe) follows the replay; both use the same bucket plan and give the same bits (tests/test_mpu_cpu.py).
+    transport = None if backend == "nccl" else torch.float32
+    reducer = None
+    if multi and (a.tp > 1 or a.no_graph):
+        reducer = mpu.OverlappedGradReducer(params, group=dp_group, transport_dtype=transport, even_if_alone=multi)
+
     def reduce_and_update():
-        mpu.allreduce_gradients(params, group=dp_group, transport_dtype=None if backend == "nccl" else torch.float32,
-                                even_if_alone=multi)
+        if reducer is not None:
+            reducer.finish()
+        else:
+            mpu.allreduce_gradients(params, group=dp_group, transport_dtype=transport, even_if_alone=multi)
         opt.step()  # clip + Adam: two launches (csrc/optimizer.hip)
 
     def step(i):  # eager launches

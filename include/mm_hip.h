@@ -159,7 +159,7 @@ int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bia
                int M, int N, int K, int lda, int ldb, int ldc, int epilogue, int dtype, void* stream);
 
 /* Host-only: name of the kernel mm_gemm_nt dispatches for a contiguous (lda = ldb = K), 16-byte aligned problem of this shape
- * ("gemm_nt_256_k", "gemm_nt_128_k" or "gemm_nt_generic_k") - so that a profile row can be matched to a call. */
+ * ("gemm_nt_pp_k<256>", "gemm_nt_pp_k<128>", "gemm_nt_128_k" or "gemm_nt_generic_k") - so that a profile row can be matched to a call. */
 const char* mm_gemm_nt_kernel_name(int M, int N, int K, int epilogue);
 
 /* The QKV projection with the rotary embedding as its epilogue: C = rotary(A B^T + bias) - ColumnParallelLinear
@@ -337,15 +337,6 @@ int mm_adam_chunk_elems(void);
 int mm_adam_step(void* const* params, const void* const* grads, float* master, float* exp_avg, float* exp_avg_sq,
                  const void* chunks, int nchunks, float* partial, int* step, float* grad_norm_out, float lr,
                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, int bias_correction, int dtype, void* stream);
-
-/* ------------------------------------------------------------------ test-only hardware probe
- * One wave reads a [16][64] 16-bit LDS tile with ds_read_b64_tr_b16; out: [64 lanes][4].  No reference counterpart. */
-int mm_debug_probe_tr_read(void* out, const void* in, const int* row0, const int* col0, void* stream);
-/* Developer decomposition of the 256x256 GEMM kernel (tools/decompose_gemm256.py): bf16, contiguous operands, M and N multiples
- * of 256; dbg bit 0 = no global->LDS loads in the K loop, bit 1 = no LDS fragment reads, bit 2 = no epilogue, bit 3 = no MFMA.
- * Results are meaningless unless dbg == 0.  No reference counterpart. */
-int mm_debug_gemm256(void* C, void* aux, const void* A, const void* B, const void* bias, int M, int N, int K, int gelu, int dbg,
-                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -79,9 +79,14 @@ PROTOTYPES = {
     "mm_dropout_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p]),
     "mm_adam_chunk_elems": (c_int, []),
     "mm_adam_step": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p] + [c_float] * 5 + [c_int, c_int, c_void_p]),
+}
+
+# developer library only (csrc/mm_hip_dev.h, `make DEV=1`): never exported by libmm_hip.so
+DEV_PROTOTYPES = {
     "mm_debug_gemm256": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "mm_debug_probe_tr_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
+DEV_LIB_PATH = os.path.join(_HERE, "libmm_hip_dev.so")
 
 _lib = None
 
@@ -104,6 +109,40 @@ def get_lib():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def _bind(path, protos):
+    import torch  # noqa: F401  (one HIP runtime per process: see get_lib)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class use_dev_lib:
+    """TESTS AND TOOLS ONLY: route every call of this package through the developer library (libmm_hip_dev.so, `make DEV=1`:
+    the product's sources plus the MM_GEMMPP / MM_GEMM256 kernel-forcing switches, the superseded 256x256 GEMM and the
+    mm_debug_* probes) - as a context manager, or permanently with use_dev_lib().enter().  The product never calls this."""
+
+    def __init__(self):
+        if not os.path.exists(DEV_LIB_PATH):
+            raise RuntimeError(f"{DEV_LIB_PATH} is missing: build it with `make -C multimodal_amd/csrc DEV=1`")
+        self._dev = _bind(DEV_LIB_PATH, {**PROTOTYPES, **DEV_PROTOTYPES})
+        self._prev = None
+
+    def enter(self):
+        global _lib
+        self._prev, _lib = _lib, self._dev
+        return self._dev
+
+    __enter__ = enter
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self._prev
+        return False
 
 
 def check(rc, what=""):

@@ -79,8 +79,8 @@ __device__ __forceinline__ float half_sum(float x) {
 // model-parallel rng tracker's fork).  The keep decision of probability element (batch*head, q, key) is a pure function of the
 // tracker's device-resident Philox-style state {seed, base offset}, the launch's position `pos` inside the step and the element's
 // coordinates, so the forward and both backward kernels regenerate the same mask and nothing of size s x s is stored:
-//     key32 = mix64(seed, offset + pos, batch * np + head)                       (per workgroup)
-//     h     = hash32((q * ceil(s / 2) + (key >> 1)) ^ key32)                      (one 32-bit hash per key PAIR)
+//     key64 = mix64(seed, offset + pos, batch * np + head)                       (per workgroup)
+//     h     = hash32(hash32((q * ceil(s / 2) + (key >> 1)) ^ key64.lo) + key64.hi) (one keyed 32-bit hash per key PAIR)
 //     keep  = ((key & 1) ? h >> 16 : h & 0xffff) >= thr,  thr = round(p * 65536)  (p is quantised to 1/65536)
 // and kept probabilities are scaled by 1 / (1 - thr / 65536).  mm_attn_dropout_mask writes the same mask as bytes (the tests'
 // oracle applies it explicitly).  The reference draws its mask from the device generator; the two streams cannot match
@@ -95,23 +95,32 @@ __device__ __forceinline__ uint32_t drop_hash(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint32_t drop_key(const DropArgs& da, uint32_t bh) {
+// 64-bit key of a (seed, offset + pos, batch * np + head) triple.  Both halves enter the per-element hash at different rounds
+// (below), so two launches / heads whose keys differ in ANY bit draw unrelated masks: with a single 32-bit key XOR-ed into the
+// index every mask would be a relabelled view of one 2^32-entry table, and a 32-bit birthday collision (expected after ~65k
+// (head, launch) pairs = ~50 steps of the 410M shape) would repeat a whole mask.
+struct DropKey {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ DropKey drop_key(const DropArgs& da, uint32_t bh) {
     unsigned long long z = da.st[0] + 0x9E3779B97F4A7C15ull * (da.st[1] + da.pos + 1ull);
     z ^= (unsigned long long)(bh + 1u) * 0xD1B54A32D192ED03ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
-    return (uint32_t)(z ^ (z >> 32));
+    return DropKey{(uint32_t)z, (uint32_t)(z >> 32)};
 }
-// the 32 random bits of key pair (key >> 1) of query row q; qh = q * ceil(s / 2)
-__device__ __forceinline__ uint32_t drop_bits(uint32_t key32, uint32_t qh, int key) { return drop_hash((qh + ((uint32_t)key >> 1)) ^ key32); }
-__device__ __forceinline__ bool drop_keep(uint32_t key32, uint32_t qh, int key, uint32_t thr) {
-    const uint32_t h = drop_bits(key32, qh, key);
+// the 32 random bits of key pair (key >> 1) of query row q; qh = q * ceil(s / 2): a keyed two-round hash of the pair's index
+__device__ __forceinline__ uint32_t drop_bits(DropKey k, uint32_t qh, int key) {
+    return drop_hash(drop_hash((qh + ((uint32_t)key >> 1)) ^ k.lo) + k.hi);
+}
+__device__ __forceinline__ bool drop_keep(DropKey k, uint32_t qh, int key, uint32_t thr) {
+    const uint32_t h = drop_bits(k, qh, key);
     return ((key & 1) ? (h >> 16) : (h & 0xffffu)) >= thr;
 }
 // zero the dropped ones of 16 accumulator registers whose rows are KEYS kb0 + acc_row(i, hh) of one query (forward / dQ layout:
 // registers 4g .. 4g+3 are four consecutive keys = two key pairs = two hashes)
-__device__ __forceinline__ void drop_apply_keys(f32x16& v, uint32_t key32, uint32_t qh, int kb0, int hh, uint32_t thr) {
+__device__ __forceinline__ void drop_apply_keys(f32x16& v, DropKey key32, uint32_t qh, int kb0, int hh, uint32_t thr) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int kb = kb0 + acc_row(4 * g, hh);
@@ -148,7 +157,8 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
     frag qf[NDS];
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) qf[ds] = *reinterpret_cast<const frag*>(qbase + (size_t)qrow_c * tok + 16 * ds + 8 * hh);
-    uint32_t dkey = 0, dqh = 0;
+    DropKey dkey{0, 0};
+    uint32_t dqh = 0;
     if constexpr (DROP) {
         dkey = drop_key(da, (uint32_t)blockIdx.x);  // blockIdx.x = batch * np + head
         dqh = (uint32_t)qrow_c * (uint32_t)((s + 1) >> 1);
@@ -373,7 +383,8 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
         qf[ds] = *reinterpret_cast<const frag*>(qbase + (size_t)qrow_c * tok + 16 * ds + 8 * hh);
         dof[ds] = *reinterpret_cast<const frag*>(dorow + 16 * ds + 8 * hh);
     }
-    uint32_t dkey = 0, dqh = 0;
+    DropKey dkey{0, 0};
+    uint32_t dqh = 0;
     if constexpr (DROP) {
         dkey = drop_key(da, (uint32_t)blockIdx.x);
         dqh = (uint32_t)qrow_c * (uint32_t)((s + 1) >> 1);
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
 
     const int krow = k0 + wave * 32 + r;
     const int krow_c = krow < s ? krow : s - 1;
-    uint32_t dkey = 0;
+    DropKey dkey{0, 0};
     if constexpr (DROP) dkey = drop_key(da, (uint32_t)blockIdx.x);
     frag kf[NDS], vf[NDS];
 #pragma unroll
@@ -763,7 +774,7 @@ static int launch_bwd(void* dqkv, float* delta, const void* dctx, const void* ct
 
 // the keep mask of the attention dropout as bytes [b, np, s, s] (1 = kept): the definition the kernels above implement
 __global__ __launch_bounds__(256) void attn_dropout_mask_k(uint8_t* __restrict__ keep, int s, DropArgs da) {
-    const uint32_t dkey = drop_key(da, (uint32_t)blockIdx.y);
+    const DropKey dkey = drop_key(da, (uint32_t)blockIdx.y);
     const uint32_t half_s = (uint32_t)((s + 1) >> 1);
     const size_t n = (size_t)s * s;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {

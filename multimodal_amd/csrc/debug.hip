@@ -1,5 +1,6 @@
 // debug.hip - hardware-semantics probes used only by tests (tests/test_hw_probes.py).
 #include "common.h"
+#include "mm_hip_dev.h"
 
 namespace mm {
 typedef __attribute__((ext_vector_type(4))) short s16x4;

@@ -210,10 +210,12 @@ extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, cons
         const int rc = gemm_pp_try(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, dtype, st);
         if (rc <= 0) return rc;
     }
-    {   // the earlier pipelined 256x256 kernel (gemm256.hip), kept for same-process A/B (MM_GEMMPP=-1)
+#ifdef MM_DEV
+    {   // the earlier pipelined 256x256 kernel (gemm256.hip): developer library only, for same-process A/B (MM_GEMMPP=-1)
         const int rc = gemm256_try(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, epilogue, dtype, st);
         if (rc <= 0) return rc;
     }
+#endif
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
         switch (epilogue) {
@@ -235,7 +237,10 @@ extern "C" const char* mm_gemm_nt_kernel_name(int M, int N, int K, int epilogue)
     if (K % 64 || N % 4) return "gemm_nt_generic_k";
     const int bn = gemm_pp_tile(M, N, K, K, K);
     if (bn) return bn == 256 ? "gemm_nt_pp_k<256>" : "gemm_nt_pp_k<128>";
-    return gemm256_takes(M, N, K, K, K) ? "gemm_nt_256_k" : "gemm_nt_128_k";
+#ifdef MM_DEV
+    if (gemm256_takes(M, N, K, K, K)) return "gemm_nt_256_k";
+#endif
+    return "gemm_nt_128_k";
 }
 
 extern "C" int mm_gemm_nt_qkv_rotary(void* C, const void* A, const void* B, const void* bias, const void* cos, const void* sin,
@@ -256,8 +261,10 @@ extern "C" int mm_gemm_nt_qkv_rotary(void* C, const void* A, const void* B, cons
     hipStream_t st = (hipStream_t)stream;
     int rc = gemm_pp_try(C, const_cast<void*>(cos), A, B, bias, sin, M, N, K, lda, ldb, ldc, MM_EPI_BIAS_ROTARY, dtype, st, ex);
     if (rc <= 0) return rc;
+#ifdef MM_DEV
     rc = gemm256_try(C, const_cast<void*>(cos), A, B, bias, sin, M, N, K, lda, ldb, ldc, MM_EPI_BIAS_ROTARY, dtype, st, ex);
     if (rc <= 0) return rc;
+#endif
     return dispatch_dtype(dtype, [&](auto t) -> int {
         using T = decltype(t);
         return launch_gemm<T, MM_EPI_BIAS_ROTARY>(C, const_cast<void*>(cos), A, B, bias, sin, M, N, K, lda, ldb, ldc, st, ex);

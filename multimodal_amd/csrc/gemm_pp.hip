@@ -235,6 +235,7 @@ static int launch_pp_epi(void* C, void* aux, const void* A, const void* B, const
     }
 }
 
+#ifdef MM_DEV
 template <int EPI, int DBG>
 static void launch_pp_dbg(void* C, void* aux, const void* A, const void* B, const void* bias, int M, int N, int K, hipStream_t st) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
@@ -261,12 +262,15 @@ int gemm_pp_debug(void* C, void* aux, const void* A, const void* B, const void* 
 #undef MM_DBG_CASE
     return hipGetLastError() == hipSuccess ? MM_OK : MM_ELAUNCH;
 }
+#endif  // MM_DEV
 
-// Shape policy (0 = this kernel does not take the problem, else the tile width BN).  MM_GEMMPP: developer switch, 256 / 128 force
-// that tile when legal, -1 = never.
+// Shape policy (0 = this kernel does not take the problem, else the tile width BN).  MM_GEMMPP (developer library only):
+// 256 / 128 force that tile when legal, -1 = never.
 int gemm_pp_tile(int M, int N, int K, int lda, int ldb) {
     int force = 0;
+#ifdef MM_DEV  // developer library only (make DEV=1 -> libmm_hip_dev.so): the product library has ONE dispatch policy
     if (const char* e = getenv("MM_GEMMPP")) force = atoi(e);
+#endif
     if (force < 0 || M < 256 || N < 128 || K < 128) return 0;
     // staging uses 32-bit byte offsets from the operand base
     if ((size_t)M * (size_t)lda * 2 >= (1ull << 32) || (size_t)N * (size_t)ldb * 2 >= (1ull << 32)) return 0;

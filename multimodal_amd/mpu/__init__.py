@@ -11,6 +11,6 @@ from .mappings import (copy_to_model_parallel_region, gather_from_model_parallel
                        reduce_from_model_parallel_region, scatter_to_model_parallel_region)
 from .random import checkpoint, get_cuda_rng_tracker, model_parallel_cuda_manual_seed  # noqa: F401
 from .utils import VocabUtility, divide, ensure_divisibility, split_tensor_along_last_dim  # noqa: F401
-from .data_parallel import allreduce_gradients  # noqa: F401
+from .data_parallel import OverlappedGradReducer, allreduce_gradients, plan_buckets  # noqa: F401
 from .cross_entropy import vocab_parallel_cross_entropy  # noqa: F401
 from .overlap import run_interleaved, split_batch  # noqa: F401

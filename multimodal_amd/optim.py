@@ -66,7 +66,11 @@ class FusedAdam:
         # the learning rate lives in device memory (the update kernel reads it at run time), so that a step captured in a HIP
         # graph follows a scheduler: step() uploads param_groups[0]["lr"] when it changed; before a graph REPLAY call sync_lr()
         self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
-        self._lr_host = torch.full((1,), float(lr), dtype=torch.float32).pin_memory()
+        # ring of pinned slots for the uploads: a slot is rewritten only after the copy that last read it has completed (its
+        # event), so a scheduler that changes the rate EVERY step never makes the host wait for the step in flight
+        self._lr_host = torch.full((8,), float(lr), dtype=torch.float32).pin_memory()
+        self._lr_events = [None] * 8
+        self._lr_slot = 0
         self._lr_uploaded = float(lr)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)  # pre-clip global norm of the last step
 
@@ -88,9 +92,14 @@ class FusedAdam:
         if lr != self._lr_uploaded:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("FusedAdam: the learning rate changed inside a graph capture; call sync_lr() before capturing")
-            torch.cuda.current_stream().synchronize()  # the pinned scalar may still be in flight from the last upload
-            self._lr_host[0] = lr
-            self._lr_dev.copy_(self._lr_host, non_blocking=True)
+            i = self._lr_slot = (self._lr_slot + 1) % len(self._lr_events)
+            if self._lr_events[i] is not None:
+                self._lr_events[i].synchronize()  # the upload from this slot eight changes ago: long done, returns at once
+            self._lr_host[i] = lr
+            self._lr_dev.copy_(self._lr_host[i:i + 1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._lr_events[i] = ev
             self._lr_uploaded = lr
 
     def refresh_master_from_params(self):

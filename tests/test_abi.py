@@ -30,6 +30,19 @@ def test_header_symbols_are_exported_and_bound():
         assert len(_lib.PROTOTYPES[name][1]) == nargs, f"{name}: header has {nargs} args, ctypes table {len(_lib.PROTOTYPES[name][1])}"
     assert set(_lib.PROTOTYPES) == set(funcs), "ctypes table lists symbols the header does not declare"
     assert lib.mm_target_arch() == b"gfx950"
+    # developer scaffolding stays out of the product: no mm_debug_* export, no environment lookup in the library
+    for name in _lib.DEV_PROTOTYPES:
+        assert not hasattr(lib, name), f"{name} belongs to libmm_hip_dev.so only"
+    assert b"MM_GEMMPP" not in open(_lib.LIB_PATH, "rb").read(), "the product library must not read kernel-forcing switches"
+
+
+def test_developer_library_is_a_superset():
+    from multimodal_amd import _lib
+    if not os.path.exists(_lib.DEV_LIB_PATH):
+        pytest.skip("libmm_hip_dev.so not built (make -C multimodal_amd/csrc DEV=1)")
+    dev = _lib.use_dev_lib()._dev
+    for name in list(_lib.PROTOTYPES) + list(_lib.DEV_PROTOTYPES):
+        assert hasattr(dev, name), name
 
 
 def test_host_only_entry_points_and_argument_errors():

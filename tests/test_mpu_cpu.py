@@ -75,6 +75,53 @@ def _worker_dp(rank, world, port):
     torch.distributed.destroy_process_group()
 
 
+def _worker_dp_overlap(rank, world, port):
+    """OverlappedGradReducer (hooks fire during the backward, one all-reduce per bucket as soon as its last gradient exists)
+    against the post-backward allreduce_gradients on the same model and data: bit-identical gradients."""
+    _init(rank, world, port)
+    from multimodal_amd import mpu
+    from multimodal_amd.mpu.data_parallel import OverlappedGradReducer, plan_buckets
+    mpu.initialize_model_parallel(1)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+                                torch.nn.Linear(32, 8))
+    model[2].bias.requires_grad = False                     # a frozen parameter (freeze_lm): not in the plan
+    unused = torch.nn.Parameter(torch.zeros(5))             # trainable but never used: its bucket only closes in finish()
+    params = [p for p in model.parameters() if p.requires_grad] + [unused]
+    torch.manual_seed(100 + rank)                           # different data per replica
+    x = torch.randn(12, 16)
+
+    def backward():
+        for p in params:
+            p.grad = None
+        model(x).pow(2).sum().backward()
+
+    group = mpu.get_data_parallel_group()
+    backward()
+    local = [p.grad.clone() for p in params[:-1]]
+    mpu.allreduce_gradients(params, group=group, bucket_bytes=1024)
+    post = [p.grad.clone() for p in params[:-1]]
+    assert any(not torch.equal(a, b) for a, b in zip(local, post))  # the replicas' gradients did differ
+    red = OverlappedGradReducer(params, group=group, bucket_bytes=1024)
+    assert red.buckets == plan_buckets(params, 1024) and len(red.buckets) >= 3
+    for step in range(2):                                   # re-armed by finish(): a second step works the same way
+        backward()
+        red.finish()
+        for a, p in zip(post, params[:-1]):
+            assert torch.equal(a, p.grad), step
+        assert unused.grad is None
+    assert red.launched_in_backward >= 2 * (len(red.buckets) - 1)   # all but the bucket holding the unused parameter
+    red.remove()
+    backward()
+    assert all(torch.equal(a, p.grad) for a, p in zip(local, params[:-1]))  # hooks gone: plain local gradients again
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_overlapped_gradient_reducer_equals_post_backward_allreduce_world2():
+    mp.spawn(_worker_dp_overlap, args=(2, _free_port()), nprocs=2, join=True)
+
+
 @pytest.mark.parametrize("fp32_allreduce", [False, True])
 def test_tensor_parallel_mappings_world2(fp32_allreduce):
     mp.spawn(_worker_tp, args=(2, _free_port(), fp32_allreduce), nprocs=2, join=True)

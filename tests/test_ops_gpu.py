@@ -36,14 +36,15 @@ def ulp_close(a, b, dtype, ulps=1, atol=1e-6, frac=1e-3):
 # ------------------------------------------------------------------ hardware probe
 def test_tr_read_semantics(ops, cuda_device):
     """ds_read_b64_tr_b16: lane i of a 16-lane group receives column i of a 4-row x 16-col block, row q in element q."""
-    import ctypes
-    from multimodal_amd._lib import get_lib, check
+    from multimodal_amd import _lib
+    from multimodal_amd._lib import check
+    dev_lib = _lib.use_dev_lib()._dev  # the probe lives in the developer library only (csrc/mm_hip_dev.h)
     tile = torch.arange(16 * 64, dtype=torch.int16).view(16, 64)
     row0 = torch.tensor([0, 4, 8, 12], dtype=torch.int32)
     col0 = torch.tensor([0, 16, 32, 48], dtype=torch.int32)
     out = torch.zeros(64, 4, dtype=torch.int16, device=cuda_device)
     d_tile, d_row0, d_col0 = tile.to(cuda_device), row0.to(cuda_device), col0.to(cuda_device)  # keep alive across the call
-    check(get_lib().mm_debug_probe_tr_read(out.data_ptr(), d_tile.data_ptr(), d_row0.data_ptr(), d_col0.data_ptr(),
+    check(dev_lib.mm_debug_probe_tr_read(out.data_ptr(), d_tile.data_ptr(), d_row0.data_ptr(), d_col0.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream))
     out = out.cpu()
     for lane in range(64):
@@ -306,7 +307,7 @@ def test_gemm_exact_small_integers(ops, cuda_device):
     assert torch.equal(out.float().cpu(), ref.bfloat16().float())
 
 
-GEMM_KINDS = {  # developer switches of the dispatch (csrc/gemm.hip): which MFMA kernel takes every legal shape
+GEMM_KINDS = {  # switches of the DEVELOPER library's dispatch (make DEV=1, csrc/gemm.hip): which MFMA kernel takes every legal shape
     0: {},                                                # the library's own shape policy
     -1: {"MM_GEMMPP": "-1", "MM_GEMM256": "-1"},          # the 128x128 kernel (gemm.hip)
     1: {"MM_GEMMPP": "-1", "MM_GEMM256": "1"},            # the earlier pipelined 256x256 kernel (gemm256.hip)
@@ -317,7 +318,12 @@ GEMM_KINDS = {  # developer switches of the dispatch (csrc/gemm.hip): which MFMA
 
 @pytest.fixture
 def force_gemm256():
-    """Select the GEMM kernel by GEMM_KINDS key for the duration of a test."""
+    """Select the GEMM kernel by GEMM_KINDS key for the duration of a test.  The product library has one dispatch policy and
+    reads no environment: the test runs on the developer library (libmm_hip_dev.so - the same kernels, plus the switches)."""
+    from multimodal_amd import _lib
+    ctx = _lib.use_dev_lib()
+    ctx.enter()
+
     def setv(v):
         for k in ("MM_GEMMPP", "MM_GEMM256"):
             os.environ.pop(k, None)
@@ -325,6 +331,7 @@ def force_gemm256():
     yield setv
     for k in ("MM_GEMMPP", "MM_GEMM256"):
         os.environ.pop(k, None)
+    ctx.__exit__()
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3])

@@ -6,6 +6,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_amd import _lib, ops
+_lib.use_dev_lib().enter()  # developer library (make DEV=1): the kernel-forcing switches / mm_debug_* live there only
 from tools.bench_kernels import timeit, rnd, H, DEV
 
 os.environ["MM_GEMM256"] = "1"

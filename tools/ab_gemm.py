@@ -6,6 +6,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_amd import _lib, ops
+_lib.use_dev_lib().enter()  # developer library (make DEV=1): the kernel-forcing switches / mm_debug_* live there only
 from tools.bench_kernels import timeit, rnd, T, H, DEV
 
 KINDS = [("128x128", {"MM_GEMMPP": "-1", "MM_GEMM256": "-1"}), ("256x256", {"MM_GEMMPP": "-1", "MM_GEMM256": "1"}),

@@ -6,6 +6,7 @@ import os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_amd import _lib
+_lib.use_dev_lib().enter()  # developer library (make DEV=1): the kernel-forcing switches / mm_debug_* live there only
 from tools.bench_kernels import rnd, T, H, DEV
 M, N, K = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (T, 4 * H, H)
 EPI = int(sys.argv[4]) if len(sys.argv) > 4 else _lib.EPI_BIAS_GELU_TANH

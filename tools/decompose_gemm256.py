@@ -6,6 +6,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_amd import _lib
+_lib.use_dev_lib().enter()  # developer library (make DEV=1): the kernel-forcing switches / mm_debug_* live there only
 lib = _lib.get_lib()
 names = {0: "full", 4: "no epilogue", 1: "no loads", 2: "no lds reads", 3: "no loads, no lds reads", 5: "no loads, no epilogue",
          6: "no lds reads, no epilogue", 7: "mfma + barrier only", 8: "no mfma", 12: "no mfma, no epilogue (loads + lds reads)",

@@ -9,10 +9,11 @@ OUT=$PWD/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 300 python3 /root/repo/bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench_unprofiled.log 2>&1
-tail -1 $OUT/${TAG}_bench_unprofiled.log > $OUT/${TAG}_bench_unprofiled_line.json
+grep '^{' $OUT/${TAG}_bench_unprofiled.log | tail -1 > $OUT/${TAG}_bench_unprofiled_line.json
 MM_BRANCH_STREAMS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o bench -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1
 cp /tmp/pk/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
-tail -1 $OUT/${TAG}_trace.log | grep '^{' > $OUT/${TAG}_bench_line.json || true
+# the profiler prints after the program: the bench line is the last line that STARTS with '{', not the log's last line
+(grep '^{' $OUT/${TAG}_trace.log | tail -1 > $OUT/${TAG}_bench_line.json) || true
 MM_BRANCH_STREAMS=0 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.log 2>&1
 python3 /root/repo/tools/pmc_by_kernel.py /tmp/pf FETCH_SIZE > $OUT/${TAG}_pmc_fetch_by_kernel.csv
 MM_BRANCH_STREAMS=0 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_write.log 2>&1
