@@ -158,6 +158,18 @@ enum {
 int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual,
                int M, int N, int K, int lda, int ldb, int ldc, int epilogue, int dtype, void* stream);
 
+/* mm_gemm_nt (epilogue MM_EPI_NONE, bias NULL, no residual) for shapes whose 256 x 256 output tiles would occupy at most
+ * half of the 256 CUs: two workgroups per tile, each over half of K, exchange fp32 partials of half a tile through `workspace`
+ * inside the launch and both finish half of it.  mm_gemm_nt_splitk_workspace_bytes returns the workspace size in bytes, or 0
+ * when the shape does not qualify (M, N multiples of 256 with 64..128 tiles, K a multiple of 128 and >= 8192: the LM head's
+ * data gradient; at the layer GEMMs' K <= 4096 the exchange costs more than it gains) - then use mm_gemm_nt.  Same F.linear contract (megatron/mpu/layers.py:557,745); sums in a different order than mm_gemm_nt (fp32
+ * partials of the two K halves are added once).  The first bytes of the workspace hold the hand-off flags; the call zeroes
+ * them on `stream`.  Calls that share a workspace must not overlap.  The two workgroups of a tile wait for each other with a
+ * bounded spin; should a partner never run, its half tile is written as NaN (never as a wrong number). */
+size_t mm_gemm_nt_splitk_workspace_bytes(int M, int N, int K);
+int mm_gemm_nt_splitk(void* C, const void* A, const void* B, const void* bias, void* workspace, int M, int N, int K,
+                      int lda, int ldb, int ldc, int epilogue, int dtype, void* stream);
+
 /* Host-only: name of the kernel mm_gemm_nt dispatches for a contiguous (lda = ldb = K), 16-byte aligned problem of this shape
  * ("gemm_nt_pp_k<256>", "gemm_nt_pp_k<128>", "gemm_nt_128_k" or "gemm_nt_generic_k") - so that a profile row can be matched to a call. */
 const char* mm_gemm_nt_kernel_name(int M, int N, int K, int epilogue);

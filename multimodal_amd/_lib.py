@@ -47,6 +47,8 @@ PROTOTYPES = {
     "mm_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "mm_gptj_combine": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
     "mm_gemm_nt": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
+    "mm_gemm_nt_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mm_gemm_nt_splitk": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "mm_gemm_nt_kernel_name": (ctypes.c_char_p, [c_int, c_int, c_int, c_int]),
     "mm_gemm_nt_qkv_rotary": (c_int, [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
     "mm_gemm_tn_splits": (c_int, [c_int, c_int, c_int]),

@@ -55,6 +55,16 @@ __device__ __forceinline__ void mfma_prio(int on) {
     if (on) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
 }
+// the same on top of a per-workgroup base priority (heavy causal blocks 2, light ones 0): variant builds only
+__device__ __forceinline__ void mfma_prio_b(int on, bool heavy) {
+    if (heavy) {
+        if (on) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(2);
+    } else {
+        if (on) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+}
 
 // Combine a value with the one held by the lane 32 away (the other half of the wave) without the LDS round trip of
 // ds_bpermute: v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32 of its second, so with
@@ -146,6 +156,14 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
     __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES];  // [buf][K | V]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int bi = blockIdx.x / np, hi = blockIdx.x % np;  // head-fast grid: see launch_fwd
+    // Workgroups of the heavier half of the causal triangle (grid y = 0 is the heaviest block) run at base priority 2, the lighter
+    // half at 0, the MFMA groups one above the base (mfma_prio_b): the makespan of the launch is the longest workgroup's
+    // chain of tiles, and that chain slows down threefold when its waves share their SIMDs evenly with two light workgroups.
+    // Same-box A/B (round 3): 54.2 -> 52.7 us.  (Pairing block y with block nblk-1-y in one workgroup - equal work everywhere,
+    // 512 workgroups = two per CU - measured 57.6 us: the third wave per SIMD is worth more than the balance.)
+    const bool heavy = MODE == 0 && (int)blockIdx.y * 2 < (int)gridDim.y;
+#define FWD_PRIO(x) mfma_prio_b(x, heavy)
+    FWD_PRIO(0);
     const int q0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 128;  // heaviest (latest) query blocks first
     const size_t tok = (size_t)b * np * 3 * HD;                   // elements between sequence positions
     const u16* qbase = qkv + ((size_t)bi * np + hi) * 3 * HD;
@@ -188,18 +206,54 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) pin(qf[ds]);
 
+#ifndef MM_AB_FWD_DBG  // decomposition builds (wrong results, same addresses): 1 = no barrier in the loop, 2 = no tile fetch / LDS
+#define MM_AB_FWD_DBG 0  // store in the loop, 4 = no softmax arithmetic (P = S)
+#endif
+    constexpr int DBG = MM_AB_FWD_DBG;
     for (int j = 0; j < ntiles; ++j) {
         const int cur = j & 1;
         const char* ks = smem + cur * 2 * TL::BYTES;
         const char* vs = ks + TL::BYTES;
-        if (j + 1 < ntiles) {
+        if (!(DBG & 2) && j + 1 < ntiles) {
             tile_load<HD>(kreg, kbase, tok, (j + 1) * 64, s, tid);
             tile_load<HD>(vreg, vbase, tok, (j + 1) * 64, s, tid);
         }
         const int kv0 = j * 64;
         if (MODE == 1 || kv0 <= wave_last) {  // wave-uniform: skip key tiles entirely above this wave's diagonal
             f32x16 sacc[2];
-            mfma_prio(1);
+#ifdef MM_AB_FWD_NO_HOIST  // (A/B variant builds only)
+            constexpr bool HOIST = false;
+#else
+            constexpr bool HOIST = HD == 64;  // head size 128: the fragments of a whole tile do not fit beside three waves per SIMD
+#endif
+            frag vfr0[2][NDB];
+            if constexpr (HOIST) {
+                // every K fragment of the tile is requested before the first MFMA (the compiler's own order asks for each one
+                // just ahead of its MFMA: four exposed LDS round trips per tile), and the V fragments of the first 32 keys are
+                // requested before the softmax, which does not depend on them: 162 VGPRs, still three waves per SIMD;
+                // 54.2 -> 53.4 us in the same A/B
+                frag kfr[2][NDS];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int ds = 0; ds < NDS; ++ds) kfr[t][ds] = row_frag<T, HD>(ks, 32 * t, ds, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                FWD_PRIO(1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
+#pragma unroll
+                    for (int ds = 0; ds < NDS; ++ds) sacc[t] = M32<T>::run(kfr[t][ds], qf[ds], sacc[t]);
+                }
+                FWD_PRIO(0);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) vfr0[s2][d] = tr_frag<T, HD>(vs, 16 * s2, d, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+            FWD_PRIO(1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -207,9 +261,11 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
 #pragma unroll
                 for (int ds = 0; ds < NDS; ++ds) sacc[t] = M32<T>::run(row_frag<T, HD>(ks, 32 * t, ds, lane), qf[ds], sacc[t]);
             }
-            mfma_prio(0);
+            FWD_PRIO(0);
+            }
             // raw scores stay unscaled: max commutes with the positive scale, and p = exp2(fma(s, c, -m)) is one FMA + one exp.
             // The causal compare/select only runs on tiles that touch this wave's diagonal (wave-uniform test).
+            if constexpr ((DBG & 4) == 0) {
             if (MODE == 1) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -257,11 +313,20 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
             }
             l_run += lsum;
             m_run = m_new;
+            }
             if constexpr (DROP) {  // the row sum above is over ALL keys (softmax first, then dropout); P.V only sees the kept ones
 #pragma unroll
                 for (int t = 0; t < 2; ++t) drop_apply_keys(sacc[t], dkey, dqh, kv0 + 32 * t, hh, da.thr);
             }
-            mfma_prio(1);
+            frag vfr1[2][NDB];
+            if constexpr (HOIST) {  // the second 32 keys' V fragments: requested before the first P.V MFMA, not between them
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) vfr1[s2][d] = tr_frag<T, HD>(vs, 32 + 16 * s2, d, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            FWD_PRIO(1);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -269,16 +334,17 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
                     const frag pf = M32<T>::cvt8(sacc[t][8 * s2], sacc[t][8 * s2 + 1], sacc[t][8 * s2 + 2], sacc[t][8 * s2 + 3],
                                                  sacc[t][8 * s2 + 4], sacc[t][8 * s2 + 5], sacc[t][8 * s2 + 6], sacc[t][8 * s2 + 7]);
 #pragma unroll
-                    for (int d = 0; d < NDB; ++d) o[d] = M32<T>::run(tr_frag<T, HD>(vs, 32 * t + 16 * s2, d, lane), pf, o[d]);
+                    for (int d = 0; d < NDB; ++d)
+                        o[d] = M32<T>::run(HOIST ? (t == 0 ? vfr0[s2][d] : vfr1[s2][d]) : tr_frag<T, HD>(vs, 32 * t + 16 * s2, d, lane), pf, o[d]);
                 }
-            mfma_prio(0);
+            FWD_PRIO(0);
         }
-        if (j + 1 < ntiles) {
+        if (!(DBG & 2) && j + 1 < ntiles) {
             char* nk = smem + (cur ^ 1) * 2 * TL::BYTES;
             tile_store<HD>(nk, kreg, tid);
             tile_store<HD>(nk + TL::BYTES, vreg, tid);
         }
-        __syncthreads();
+        if (!(DBG & 1)) __syncthreads();
     }
 
     const float l_tot = half_sum(l_run);
@@ -296,6 +362,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
             }
         if (hh == 0) lse[((size_t)bi * np + hi) * s + qrow] = (m_run + __log2f(l_tot)) * kLn2;
     }
+#undef FWD_PRIO
 }
 
 // =====================================================================================  backward: gradient row store
@@ -369,6 +436,8 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int bi = blockIdx.x / np, hi = blockIdx.x % np;  // head-fast grid: see launch_fwd
     const int q0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 128;
+    // (the forward kernel's base priority by causal weight LOSES here: dq + dkv 152 -> 159-163 us with two waves per SIMD)
+#define BWD_PRIO(x) mfma_prio(x)
     const size_t tok = (size_t)b * np * 3 * HD;
     const u16* qbase = qkv + ((size_t)bi * np + hi) * 3 * HD;
     const u16* kbase = qbase + HD;
@@ -451,13 +520,13 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
                 f32x16 sacc, dpacc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sacc[i] = dpacc[i] = 0.f;
-                mfma_prio(1);
+                BWD_PRIO(1);
 #pragma unroll
                 for (int ds = 0; ds < NDS; ++ds) {
                     sacc = M32<T>::run(row_frag<T, HD>(ks, 32 * t, ds, lane), qf[ds], sacc);
                     dpacc = M32<T>::run(row_frag<T, HD>(vs, 32 * t, ds, lane), dof[ds], dpacc);
                 }
-                mfma_prio(0);
+                BWD_PRIO(0);
                 if constexpr (DROP) {  // dP = keep / (1 - p) * (dO . V): the gradient through the dropped probabilities
                     drop_apply_keys(dpacc, dkey, dqh, kv0 + 32 * t, hh, da.thr);
 #pragma unroll
@@ -498,7 +567,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
                         sacc[i] = dsv;
                     }
                 }
-                mfma_prio(1);
+                BWD_PRIO(1);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const frag dsf = M32<T>::cvt8(sacc[8 * s2], sacc[8 * s2 + 1], sacc[8 * s2 + 2], sacc[8 * s2 + 3],
@@ -506,7 +575,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k(u16* __
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) dq[d] = M32<T>::run(tr_frag<T, HD>(ks, 32 * t + 16 * s2, d, lane), dsf, dq[d]);
                 }
-                mfma_prio(0);
+                BWD_PRIO(0);
             }
         }
         if (j + 1 < ntiles) {
@@ -533,7 +602,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
     typedef Tile<HD> TL;
     typedef typename M32<T>::frag frag;
     constexpr int NDS = HD / 16, NDB = HD / 32;
-    // [buf][Q | dO] tiles, then [buf][lse2[64] | delta[64]] floats
+    // [buf][Q | dO] tiles, then [buf][lse2[64] | -delta[64]] floats
     __shared__ __attribute__((aligned(16))) char smem[4 * TL::BYTES + 2 * 2 * 64 * 4];
     float* stat = reinterpret_cast<float*>(smem + 4 * TL::BYTES);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -583,7 +652,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
     auto store_stats = [&](int buf) {
         if (tid < 64) {
             stat[buf * 128 + tid] = st_l * kLog2e;
-            stat[buf * 128 + 64 + tid] = st_d;
+            stat[buf * 128 + 64 + tid] = -st_d;  // negated: it is the INITIAL ACCUMULATOR of the dP product (below)
         }
     };
     tile_load<HD>(qreg, qbase, tok, jt0 * 64, s, tid);
@@ -614,15 +683,26 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x16 sacc, dpacc;
+                // Row constants as the initial accumulator: the registers of a lane are QUERIES here (4 consecutive rows per
+                // group), so -delta[q] comes straight from the tile's statistics in LDS into the accumulator of the dP chain
+                // and dP - delta leaves the MFMAs ready-made - 16 fewer subtractions per 32 x 32 block in a loop that the
+                // vector port, not the matrix pipe, bounds.  (Dropout scales dP before the subtraction: it keeps the zero.)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[i] = dpacc[i] = 0.f;
-                mfma_prio(1);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 nd4 = *reinterpret_cast<const f32x4*>(sl + 64 + 32 * t + 8 * g4 + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sacc[4 * g4 + e] = 0.f;
+                        dpacc[4 * g4 + e] = DROP ? 0.f : nd4[e];
+                    }
+                }
+                BWD_PRIO(1);
 #pragma unroll
                 for (int ds = 0; ds < NDS; ++ds) {
                     sacc = M32<T>::run(row_frag<T, HD>(qs, 32 * t, ds, lane), kf[ds], sacc);    // S[q][key]
-                    dpacc = M32<T>::run(row_frag<T, HD>(os, 32 * t, ds, lane), vf[ds], dpacc);  // dP[q][key]
+                    dpacc = M32<T>::run(row_frag<T, HD>(os, 32 * t, ds, lane), vf[ds], dpacc);  // dP[q][key] - delta[q]
                 }
-                mfma_prio(0);
+                BWD_PRIO(0);
                 float pv[16];
                 bool keep[16];
                 if constexpr (DROP) {  // here the lane is a KEY and the registers are queries: one hash per element
@@ -656,24 +736,27 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                             if (krow > q || q >= s) pv[i] = 0.f;
                         }
                     }
+                    if constexpr (DROP) {
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int ql = 32 * t + 8 * g4 + 4 * hh;
-                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sl + 64 + ql);
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const f32x4 nd4 = *reinterpret_cast<const f32x4*>(sl + 64 + 32 * t + 8 * g4 + 4 * hh);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int i = 4 * g4 + e;
-                            float dsv = pv[i] * (dpacc[i] - d4[e]);  // dS / scale; the scale is applied once to dK at the end
-                            asm volatile("" : "+v"(dsv));
-                            sacc[i] = dsv;
+                            for (int e = 0; e < 4; ++e) dpacc[4 * g4 + e] += nd4[e];
                         }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float dsv = pv[i] * dpacc[i];  // dS / scale (dpacc = dP - delta); the scale is applied once to dK at the end
+                        asm volatile("" : "+v"(dsv));
+                        sacc[i] = dsv;
                     }
                 } else {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int ql = 32 * t + 8 * g4 + 4 * hh;
                         const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + ql);
-                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sl + 64 + ql);
+                        f32x4 nd4 = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (DROP) nd4 = *reinterpret_cast<const f32x4*>(sl + 64 + ql);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int i = 4 * g4 + e;
@@ -681,7 +764,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                             const bool dead = (q >= s) || (krow >= s);
                             const bool mk = !dead && mask_at(mbase + (size_t)q * s, krow);
                             const float p = dead ? 0.f : fast_exp2((mk ? kMaskFill * kLog2e : sacc[i] * scale_log2e) - l4[e]);
-                            sacc[i] = mk ? 0.f : p * (dpacc[i] - d4[e]);
+                            sacc[i] = mk ? 0.f : p * (dpacc[i] + nd4[e]);  // dpacc already holds dP - delta unless DROP
                             pv[i] = p;
                         }
                     }
@@ -690,7 +773,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
 #pragma unroll
                     for (int i = 0; i < 16; ++i) pv[i] = keep[i] ? pv[i] * da.rscale : 0.f;
                 }
-                mfma_prio(1);
+                BWD_PRIO(1);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const frag pf = M32<T>::cvt8(pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3], pv[8 * s2 + 4],
@@ -703,7 +786,7 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
                         dk[d] = M32<T>::run(tr_frag<T, HD>(qs, 32 * t + 16 * s2, d, lane), dsf, dk[d]);  // dK^T += Q^T . dS
                     }
                 }
-                mfma_prio(0);
+                BWD_PRIO(0);
             }
         }
         if (j + 1 < nqt) {
@@ -720,6 +803,8 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
         store_grad_row<T, HD, 0>(krow_o + HD, dv, 1.0f, hh, nullptr, nullptr);
     }
 }
+
+#undef BWD_PRIO
 
 template <typename T, int HD>
 static int launch_fwd(void* ctx, float* lse, const void* qkv, const uint8_t* mask, int mode, int mb, int s, int b, int np,

@@ -231,6 +231,26 @@ extern "C" int mm_gemm_nt(void* C, void* aux, const void* A, const void* B, cons
     });
 }
 
+// C = A B^T (+ bias) by the split-K form of the ping-pong kernel (csrc/gemm_pp.hip): for the shapes whose 256 x 256 tiles would
+// fill half the chip or less (the N = h class at M = 8192, the LM head's data gradient with K = 50304).
+extern "C" size_t mm_gemm_nt_splitk_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return gemm_pp_splitk_workspace(M, N, K, K, K);
+}
+
+extern "C" int mm_gemm_nt_splitk(void* C, const void* A, const void* B, const void* bias, void* workspace, int M, int N, int K,
+                                 int lda, int ldb, int ldc, int epilogue, int dtype, void* stream) {
+    MM_CHECK_ARG(C && A && B && workspace, "mm_gemm_nt_splitk: null pointer");
+    MM_CHECK_ARG(M > 0 && N > 0 && K > 0, "mm_gemm_nt_splitk: M=%d N=%d K=%d must be positive", M, N, K);
+    MM_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "mm_gemm_nt_splitk: leading dimensions too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    MM_CHECK_ARG(epilogue == MM_EPI_NONE && bias == nullptr, "mm_gemm_nt_splitk: epilogue %d not supported (MM_EPI_NONE without a bias only)", epilogue);
+    MM_CHECK_ARG(gemm_pp_splitk_workspace(M, N, K, lda, ldb) != 0,
+                 "mm_gemm_nt_splitk: M=%d N=%d K=%d is not a split-K shape (mm_gemm_nt_splitk_workspace_bytes returns 0): use mm_gemm_nt", M, N, K);
+    MM_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(workspace) &&
+                     ((((uintptr_t)C) | ((uintptr_t)bias)) & 7) == 0, "mm_gemm_nt_splitk: operands must be 16-byte aligned");
+    return gemm_pp_splitk(C, A, B, bias, M, N, K, lda, ldb, ldc, workspace, epilogue, dtype, (hipStream_t)stream);
+}
+
 extern "C" const char* mm_gemm_nt_kernel_name(int M, int N, int K, int epilogue) {
     (void)epilogue;
     if (M <= 0 || N <= 0 || K <= 0) return "none";

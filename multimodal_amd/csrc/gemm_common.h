@@ -266,6 +266,10 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
 int gemm_pp_tile(int M, int N, int K, int lda, int ldb);
 int gemm_pp_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
                 int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st, const EpiExtra& ex = EpiExtra{});
+// split-K form of the ping-pong kernel (two K-slices per 256 x 256 tile): workspace bytes it needs (0: not a split-K shape)
+size_t gemm_pp_splitk_workspace(int M, int N, int K, int lda, int ldb);
+int gemm_pp_splitk(void* C, const void* A, const void* B, const void* bias, int M, int N, int K, int lda, int ldb, int ldc,
+                   void* ws, int epilogue, int dtype, hipStream_t st);
 bool gemm256_takes(int M, int N, int K, int lda, int ldb);
 int gemm256_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
                 int lda, int ldb, int ldc, int epilogue, int dtype, hipStream_t st, const EpiExtra& ex = EpiExtra{});

@@ -56,18 +56,37 @@ __device__ __forceinline__ void pp_barrier() {
 
 // DBG (developer decomposition builds only, mm_debug_gemm256 variants 16..): bit 0 = no global->LDS DMA inside the K loop, bit 1 =
 // no LDS fragment reads inside the loop, bit 2 = no epilogue.  DBG = 0 everywhere in the product.
-template <typename T, int EPI, bool RES, int BN, int DBG = 0>
+// SPLITK = 2 (BN = 256 only): two workgroups per output tile, each over half of K, for shapes with too few tiles to fill the
+// chip (the N = h class at M = 8192: 128 tiles; the LM head's data gradient: K = 50304).  The exchange is symmetric: after its
+// K loop a workgroup hands the fp32 accumulators of ONE of its two wave rows (128 x 256, 128 KiB, lane-linear 16-byte stores)
+// to its partner and finishes the other wave row with the partner's partials added, so both workgroups run an epilogue over
+// half a tile.  Hand-off per cdna_hip_programming.md Guideline 16 (R1): write-through (sc1) stores, every wave drains, workgroup barrier, one
+// lane's agent-scope flag store; the same lane polls the partner's flag (relaxed, bounded), one agent-scope acquire, barrier,
+// plain loads.  Partners sit 8 apart in dispatch order (same XCD under round-robin placement - speed only), the grid is at most
+// one workgroup per CU, and a spin that runs out raises ws_flags[timeout] instead of hanging.  own + partner is one fp32 add
+// per element either way round: the result does not depend on which side finishes a row.
+struct SplitArgs {
+    float* slabs;      // [tiles][2 (receiving slice)][4 (wave column)][128 x 64 fp32, (ni, mi, lane) order]
+    unsigned* flags;   // [tiles * 2] "my half for you is published", then [1] timeout marker; zeroed before the launch
+};
+
+template <typename T, int EPI, bool RES, int BN, int DBG = 0, int SPLITK = 1>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ A,
                                                        const u16* __restrict__ B, const u16* __restrict__ bias,
                                                        const u16* __restrict__ Rsd, int M, int N, int K, int lda, int ldb,
-                                                       int ldc, int tiles_m, int tiles_n, int group_m, EpiExtra ex) {
+                                                       int ldc, int tiles_m, int tiles_n, int group_m, EpiExtra ex,
+                                                       SplitArgs sp = SplitArgs{nullptr, nullptr}) {
     typedef PP<BN> P;
     constexpr int MI = P::MI;
     typedef typename Mfma<T>::frag frag;
+    static_assert(SPLITK == 1 || (SPLITK == 2 && BN == 256), "split-K: two slices of a 256 x 256 tile");
     __shared__ __attribute__((aligned(16))) char smem[P::LDS + 8 * 256];  // the ONLY LDS object of the kernel (+ the warming loads' dump area)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int tm, tn;
-    tile_coords(blockIdx.x, tiles_m, tiles_n, group_m, tm, tn);
+    // split-K: blocks b and b + 8 (b & 8 == 0) are the two K-slices of tile (b & 7) + 8 * (b >> 4)
+    const int slice = SPLITK == 2 ? (int)((blockIdx.x >> 3) & 1) : 0;
+    const int tidx = SPLITK == 2 ? (int)((blockIdx.x & 7) | ((blockIdx.x >> 4) << 3)) : (int)blockIdx.x;
+    tile_coords(tidx, tiles_m, tiles_n, group_m, tm, tn);
     const int bm = tm * P::BM, bn = tn * BN;
     const int wr = wave / P::WAVES_N, wc = wave % P::WAVES_N;
     const int frow = lane & 15, fq = lane >> 4;
@@ -90,9 +109,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
             goffB[i] = (uint32_t)gr * (uint32_t)(ldb * 2) + (uint32_t)((cl ^ ((r >> 1) & 7)) << 4);
         }
     }
+    const int nt = (K / 64) / SPLITK;     // K-tiles of this workgroup: slice * nt .. slice * nt + nt - 1
     auto issue = [&](int t, int stage) {  // this wave's rows of K-tile t
-        const char* ag = (const char*)A + (size_t)t * P::ROWB;
-        const char* bg = (const char*)B + (size_t)t * P::ROWB;
+        const char* ag = (const char*)A + (size_t)(slice * nt + t) * P::ROWB;
+        const char* bg = (const char*)B + (size_t)(slice * nt + t) * P::ROWB;
         char* la = smem + stage * P::STAGE + wave * 8 * P::ROWB;  // wave-uniform; HW adds lane*16
         char* lb = la + P::A_BYTES;
 #pragma unroll
@@ -140,10 +160,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    const int nt = K / 64;
     // the weight matrix on its way into the Infinity Cache (first 256 workgroups of the launch; gemm_common.h)
     touch_weight(B, N, K, ldb, blockIdx.x, min((int)gridDim.x, 256), tid, 512, smem + P::LDS + wave * 256);
+    // (Round 2 also warmed the backward epilogues' saved-tensor tile here, one dword per 128-byte line.  Round 3 A/B of exactly that,
+    // same process, interleaved, everything cold - tools/ab_two_libs.py, M=8192 N=4096 K=1024 GeLU' epilogue: 95.2 us with the warming
+    // loads, 87.8 without; whole step 20.13 -> 19.99 ms.  The 1024 scattered line fetches per workgroup delay its first K-tiles by
+    // more than the epilogue's streaming loads gain, and the counters showed the tensor fetched twice: 232 MiB against 88.  Removed;
+    // -DMM_AB_TOUCH_TILE brings it back for a variant build.)
+#ifdef MM_AB_TOUCH_TILE
     if constexpr (BN == 256 && epi_is_bwd(EPI)) touch_tile256(Rsd, ldc, bm, bn, M, N, tid, smem + P::LDS + wave * 256);
+#endif
     // ---- prologue: tiles 0 and 1 by everyone; tile 0 visible after the barrier
     issue(0, 0);
     if (nt > 1) {
@@ -191,6 +217,55 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
         if (sum == 12345.678f) C[0] = (u16)lane;
         return;
     }
+    if constexpr (SPLITK == 2) {
+        // ---- split-K exchange: wave row `slice` is finished here, wave row 1 - slice goes to the partner
+        const size_t slab = (size_t)128 * 64;
+        if (wr != slice) {
+            // write-through (sc1) 16-byte stores: the partials leave this XCD's L2 as they are written, so the publish needs no
+            // agent-scope release (an L2 write-back of 128 KiB per workgroup: MI355X_MICROARCH.md, publish-large 8.2 vs 3.0 us)
+            float* dstp = sp.slabs + (((size_t)tidx * 2 + (1 - slice)) * 4 + wc) * slab;
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(dstp, 0, (int)(slab * sizeof(float)), 0x00020000);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ni][mi]), rsrc,
+                                                           ((ni * MI + mi) * 64 + lane) * 16, 0, 16 /* sc1 */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the barrier
+        __syncthreads();
+        unsigned* lost = reinterpret_cast<unsigned*>(smem + P::LDS + 8 * 256 - 4);  // last word of the (now idle) dump area
+        if (tid == 0) {
+            __hip_atomic_store(sp.flags + tidx * 2 + (1 - slice), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0, gave_up = 0;
+            while (__hip_atomic_load(sp.flags + tidx * 2 + slice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 24)) {  // ~seconds: the partner never ran - leave a mark instead of hanging the GPU
+                    __hip_atomic_store(sp.flags + 2 * tiles_m * tiles_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = 1;
+                    break;
+                }
+            }
+            *lost = gave_up;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (wr != slice) return;
+        const bool poisoned = *lost != 0u;  // the partner's partials never came: the half tile is written as NaN, never as a wrong number
+        const f32x4* src = reinterpret_cast<const f32x4*>(sp.slabs + (((size_t)tidx * 2 + slice) * 4 + wc) * slab) + lane;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] += src[(ni * MI + mi) * 64];
+        if (poisoned) {
+            const float qnan = __builtin_nanf("");
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{qnan, qnan, qnan, qnan};
+        }
+    }
     // ---- epilogue (coalesced through a wave-private LDS region: MI*16 rows x 128 B).  Group 0 starts it one phase before
     // group 1, whose last phase computes from registers; nobody touches the stages any more.
     epilogue_staged<T, EPI, RES, MI>(acc, smem + wave * (MI * 16 * 128), bm + wr * P::WM, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd,
@@ -233,6 +308,56 @@ static int launch_pp_epi(void* C, void* aux, const void* A, const void* B, const
         case MM_EPI_GELU_TANH_BWD: return launch_pp<T, MM_EPI_GELU_TANH_BWD, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
         default: return launch_pp<T, MM_EPI_GELU_ERF_BWD, BN>(C, aux, A, B, bias, residual, M, N, K, lda, ldb, ldc, st, ex);
     }
+}
+
+// ---- split-K (two K-slices per 256 x 256 tile): shape policy, workspace size, launch
+__global__ void pp_zero_flags_k(unsigned* __restrict__ p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+
+static size_t pp_splitk_flag_bytes(int tiles) { return (((size_t)tiles * 2 + 1) * 4 + 255) & ~(size_t)255; }
+
+// 0 = not a split-K shape.  Wanted where 256 x 256 tiles are too few for the 256 CUs but two slices each fill them (every
+// workgroup resident at once: the partners wait for each other) and each slice still has a K loop worth its prologue.
+size_t gemm_pp_splitk_workspace(int M, int N, int K, int lda, int ldb) {
+    // K >= 8192: measured on MI355X at M = 8192, N = 1024 (tools/ab_splitk.py, cold operands) the exchange (32 MiB of fp32 partials
+    // out and in, all 256 workgroups at the same moment: ~13 us) costs more than the 256 x 256 tiles gain at K = 2048 / 3072 / 4096
+    // (42.5 / 57.3 / 72.9 us against 36.3 / 54.5 / 70.3 for the 128 x 128 kernel) and far less at K = 50304 (659 against 865 us)
+#ifndef MM_AB_SPLITK_MINK  // (A/B variant builds only: make EXTRA=-DMM_AB_SPLITK_MINK=2048)
+#define MM_AB_SPLITK_MINK 8192
+#endif
+    if (M % 256 || N % 256 || K % 128 || K < MM_AB_SPLITK_MINK) return 0;
+    if ((size_t)M * (size_t)lda * 2 >= (1ull << 32) || (size_t)N * (size_t)ldb * 2 >= (1ull << 32)) return 0;
+    const long tiles = (long)(M / 256) * (N / 256);
+    if (tiles % 8 || tiles < 64 || tiles > 128) return 0;
+    return pp_splitk_flag_bytes((int)tiles) + (size_t)tiles * 2 * 4 * 128 * 64 * sizeof(float);
+}
+
+template <typename T, int EPI>
+static int launch_pp_splitk(void* C, const void* A, const void* B, const void* bias, int M, int N, int K, int lda, int ldb, int ldc,
+                            void* ws, hipStream_t st) {
+    const int tiles_m = M / 256, tiles_n = N / 256, tiles = tiles_m * tiles_n;
+    int group_m = (tiles / 8) / tiles_n;
+    group_m = group_m < 1 ? 1 : (group_m > 8 ? 8 : group_m);
+    unsigned* flags = (unsigned*)ws;
+    // a kernel, not hipMemsetAsync: under stream capture the memset was not replayed (see prefix.hip)
+    pp_zero_flags_k<<<1, 256, 0, st>>>(flags, 2 * tiles + 1);
+    MM_CHECK_LAUNCH();
+    SplitArgs sp{(float*)((char*)ws + pp_splitk_flag_bytes(tiles)), flags};
+    gemm_nt_pp_k<T, EPI, false, 256, 0, 2><<<dim3(2 * tiles), dim3(512), 0, st>>>((u16*)C, nullptr, (const u16*)A, (const u16*)B,
+                                                                                 (const u16*)bias, nullptr, M, N, K, lda, ldb, ldc,
+                                                                                 tiles_m, tiles_n, group_m, EpiExtra{}, sp);
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+}
+
+int gemm_pp_splitk(void* C, const void* A, const void* B, const void* bias, int M, int N, int K, int lda, int ldb, int ldc,
+                   void* ws, int epilogue, int dtype, hipStream_t st) {
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        (void)epilogue;  // MM_EPI_NONE only (the bias epilogue's extra registers spill beside the exchange: not instantiated)
+        return launch_pp_splitk<T, MM_EPI_NONE>(C, A, B, bias, M, N, K, lda, ldb, ldc, ws, st);
+    });
 }
 
 #ifdef MM_DEV

@@ -288,6 +288,7 @@ def gptj_combine(x, attn, attn_bias, mlp, mlp_bias):
 
 
 # ---------------------------------------------------------------------------- GEMM
+GEMM_SPLITK = True        # plain GEMMs of split-K shapes go to mm_gemm_nt_splitk (False: always mm_gemm_nt; A/B tools flip it)
 GEMM_EVENT_PROBE = None  # set by bench.py to {"epilogue": code, "events": []} to time one kernel instantiation in situ
 
 
@@ -308,6 +309,15 @@ def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, wa
     if bias is not None and epilogue == _lib.EPI_NONE:
         epilogue = _lib.EPI_BIAS
     c = torch.empty(M, N, dtype=a.dtype, device=a.device) if out is None else out
+    if GEMM_SPLITK and epilogue == _lib.EPI_NONE and bias is None and residual is None and not want_aux and c.is_contiguous():
+        # too few 256 x 256 tiles for the chip (the N = h class at M = 8192, the LM head's data gradient): two K-slices per
+        # tile exchange partials inside the launch (csrc/gemm_pp.hip)
+        ws_bytes = get_lib().mm_gemm_nt_splitk_workspace_bytes(M, N, K)
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+            check(get_lib().mm_gemm_nt_splitk(c.data_ptr(), a2.data_ptr(), b.data_ptr(), None, ws.data_ptr(), M, N, K, K, K, N,
+                                              epilogue, dtype_code(a.dtype), _stream()), "gemm_nt_splitk")
+            return c.view(*a.shape[:-1], N)
     aux = None
     if epilogue in (_lib.EPI_BIAS_GELU_TANH, _lib.EPI_BIAS_GELU_ERF):
         aux = torch.empty(M, N, dtype=a.dtype, device=a.device)

@@ -394,6 +394,56 @@ def test_gemm_nt_256_race_screen(ops, cuda_device, force_gemm256, variant, N, K)
     assert float((d > 0).float().mean()) < 0.05   # same products, different fp32 summation order: rare 1-ulp flips only
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 8192), (8192, 1024, 8192 + 128), (8192, 512, 50304)])
+def test_gemm_nt_splitk(ops, cuda_device, M, N, K):
+    """In-kernel split-K (two workgroups per 256 x 256 tile exchange fp32 partials, csrc/gemm_pp.hip): against fp64, bit for bit
+    run to run (a partial read before its partner published it would differ), and to rounding against mm_gemm_nt."""
+    lib = ops.get_lib()
+    assert lib.mm_gemm_nt_splitk_workspace_bytes(M, N, K) > 0
+    assert lib.mm_gemm_nt_splitk_workspace_bytes(M, N, 4096) == 0      # the layer GEMMs stay on mm_gemm_nt
+    assert lib.mm_gemm_nt_splitk_workspace_bytes(M + 8, N, K) == 0
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=cuda_device).bfloat16()
+    b = (torch.randn(N, K, device=cuda_device) / K ** 0.5).bfloat16()
+    ops.GEMM_SPLITK = False
+    try:
+        base = ops.gemm_nt(a, b)
+    finally:
+        ops.GEMM_SPLITK = True
+    first = ops.gemm_nt(a, b)
+    for _ in range(10):
+        assert torch.equal(ops.gemm_nt(a, b), first)
+    ref = torch.cat([a[i:i + 1024].double() @ b.double().t() for i in range(0, M, 1024)])
+    err = (first.double() - ref).abs()
+    assert bool((err <= 2.0 ** -7 * ref.abs() + 2e-2).all()), f"max err {float(err.max())}"
+    d = (first.float() - base.float()).abs()
+    assert float(d.max()) <= 2.0 ** -6 * float(base.float().abs().max())
+    assert float((d > 0).float().mean()) < 0.05
+
+
+def test_gemm_nt_splitk_exact_integers(ops, cuda_device):
+    """Small-integer operands: every product, both K-slice partials and their sum are exact in fp32."""
+    M, N, K = 4096, 1024, 8192
+    a = (torch.arange(M * K, device=cuda_device).view(M, K) % 7 - 3).float()
+    b = ((torch.arange(N * K, device=cuda_device).view(N, K) * 5) % 11 - 5).float()
+    assert ops.get_lib().mm_gemm_nt_splitk_workspace_bytes(M, N, K) > 0
+    out = ops.gemm_nt(a.bfloat16(), b.bfloat16())
+    ref = torch.cat([a[i:i + 512].double() @ b.double().t() for i in range(0, M, 512)])
+    assert torch.equal(out.float(), ref.float().bfloat16().float())
+
+
+def test_gemm_nt_splitk_rejects(ops, cuda_device):
+    lib = ops.get_lib()
+    a = torch.zeros(4096, 4096, device=cuda_device).bfloat16()
+    w = torch.zeros(1024, 4096, device=cuda_device).bfloat16()
+    c = torch.empty(4096, 1024, device=cuda_device).bfloat16()
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=cuda_device)
+    from multimodal_amd import _lib
+    rc = lib.mm_gemm_nt_splitk(c.data_ptr(), a.data_ptr(), w.data_ptr(), None, ws.data_ptr(), 4096, 1024, 4096, 4096, 4096, 1024,
+                               _lib.EPI_NONE, ops.dtype_code(torch.bfloat16), None)
+    assert rc != 0   # not a split-K shape: the caller is sent to mm_gemm_nt
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 8, 48), (1024, 1024, 4), (5, 7, 3), (130, 36, 100)])
 def test_gemm_generic_fallback_ragged_shapes(ops, cuda_device, M, N, K):
     """Shapes the MFMA kernel does not take (K % 64 != 0, N % 4 != 0) run the generic kernel with the same semantics."""

@@ -9,12 +9,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-template <int KIND, bool DO_A, bool DO_B, bool SWAP>
+// CH = independent accumulator chains of group A's MFMAs (1: every MFMA waits for the one before it, as a 4-deep S = K.Q^T chain does)
+template <int KIND, bool DO_A, bool DO_B, bool SWAP, int CH = 2>
 __global__ __launch_bounds__(512, 1) void k(float* out, long long* cyc, int nseg, int nm, int nv) {
     const int wave = threadIdx.x >> 6;
     const bool is_a = SWAP ? (wave >= 4) : (wave < 4);
-    f32x16 acc0, acc1;
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    f32x16 acc0, acc1, acc2, acc3;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
     bf16x8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * (threadIdx.x - i)); }
     float v[8];
@@ -25,9 +26,18 @@ __global__ __launch_bounds__(512, 1) void k(float* out, long long* cyc, int nseg
     for (int s = 0; s < nseg; ++s) {
         if (is_a) {
             if (DO_A)
-                for (int i = 0; i < nm; i += 2) {
+                for (int i = 0; i < nm; i += 4) {
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
+                    if (CH == 1) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc0, 0, 0, 0);
+                    else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
+                    if (CH == 4) {
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc3, 0, 0, 0);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+                        if (CH == 1) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc0, 0, 0, 0);
+                        else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
+                    }
                 }
         } else if (DO_B) {
             for (int i = 0; i < nv; i += 8) {
@@ -73,16 +83,16 @@ __global__ __launch_bounds__(512, 1) void k(float* out, long long* cyc, int nseg
         __builtin_amdgcn_s_barrier();
     }
     const long long t1 = __builtin_readcyclecounter();
-    float r = acc0[0] + acc1[5];
+    float r = acc0[0] + acc1[5] + acc2[3] + acc3[7];
     for (int i = 0; i < 8; ++i) r += v[i];
     for (int i = 0; i < 4; ++i) r += p[i][0] + p[i][1];
     if (r == 1234.5678f) out[threadIdx.x] = r;
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
-template <int KIND, bool A, bool B, bool SWAP> double run(int nseg, int nm, int nv, float* out, long long* cyc) {
+template <int KIND, bool A, bool B, bool SWAP, int CH = 2> double run(int nseg, int nm, int nv, float* out, long long* cyc) {
     for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL((k<KIND, A, B, SWAP>), dim3(256), dim3(512), 0, 0, out, cyc, nseg, nm, nv);
+        hipLaunchKernelGGL((k<KIND, A, B, SWAP, CH>), dim3(256), dim3(512), 0, 0, out, cyc, nseg, nm, nv);
         hipDeviceSynchronize();
     }
     long long h;
@@ -104,6 +114,12 @@ int main() {
                run<K, false, true, false>(nseg, nm, nv, out, cyc), run<K, true, true, false>(nseg, nm, nv, out, cyc), \
                run<K, true, true, true>(nseg, nm, nv, out, cyc));
         ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7)
+        // the same with ONE dependent accumulator chain and with four independent ones in group A (v_fma_f32 and v_exp_f32 in group B)
+#define ROWCH(K, C)                                                                                                         \
+        printf("   chains=%d %-14s A only %.0f   B only %.0f   A+B %.0f   swapped %.0f\n", C, names[K],                       \
+               run<K, true, false, false, C>(nseg, nm, nv, out, cyc), run<K, false, true, false, C>(nseg, nm, nv, out, cyc), \
+               run<K, true, true, false, C>(nseg, nm, nv, out, cyc), run<K, true, true, true, C>(nseg, nm, nv, out, cyc));
+        ROWCH(0, 1) ROWCH(1, 1) ROWCH(0, 4) ROWCH(1, 4)
     }
     return 0;
 }
