@@ -53,7 +53,7 @@ def roofline_from_probe(cfg, probe, tp=1):
     h = cfg["hidden_size"]
     N = 4 * h // tp
     # (with tensor parallelism the stack walks the layers in sub-batches - mpu/overlap.py - so a launch covers T / chunks rows)
-    hits = [(a.elapsed_time(b), M) for a, b, M, Nn, K in probe["events"] if (Nn, K) == (N, h)]
+    hits = [(a.elapsed_time(b), M) for a, b, M, Nn, K, epi in probe["events"] if (Nn, K) == (N, h) and epi == probe["epilogue"]]
     if not hits:
         raise RuntimeError("bench.py: no launch of the roofline kernel (N=%d K=%d, epilogue %d) was seen by the event probe"
                            % (N, h, probe["epilogue"]))
@@ -69,6 +69,29 @@ def roofline_from_probe(cfg, probe, tp=1):
             "frac": round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), "avg_kernel_ms": round(avg_ms, 4),
             "median_kernel_ms": round(ms[len(ms) // 2], 4), "launches_timed": len(ms), "flops_per_launch": flops,
             "traffic": pmc_traffic(label)}
+
+
+def roofline_by_time(probe):
+    """The kernel with the largest share of the step's time is not the roofline kernel above but `gemm_nt_128_k`, which takes every
+    plain N = h GEMM (attention dense, 4h->h, and the data gradients of QKV / dense / h->4h): the same in-situ HIP events, all of
+    its launches in the timed steps, launch-weighted (total FLOPs / total kernel time) and per shape."""
+    from multimodal_amd import ops, _lib
+    by_shape = {}
+    for e0, e1, M, N, K, epi in probe["events"]:
+        if epi != _lib.EPI_NONE or ops.gemm_nt_kernel_name(M, N, K, epi) != "gemm_nt_128_k":
+            continue
+        by_shape.setdefault((M, N, K), []).append(e0.elapsed_time(e1))
+    if not by_shape:
+        return None
+    flops = sum(2.0 * M * N * K * len(v) for (M, N, K), v in by_shape.items())
+    ms = sum(sum(v) for v in by_shape.values())
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_nt_128_k<bf16, plain> (the N = h class)", "achieved": round(achieved, 2),
+            "peak": PEAK_BF16_FLOPS / 1e12, "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_FLOPS / 1e12), 4),
+            "launches_timed": sum(len(v) for v in by_shape.values()), "kernel_ms_total": round(ms, 3),
+            "shapes": [{"M": M, "N": N, "K": K, "launches": len(v), "avg_kernel_ms": round(sum(v) / len(v), 4),
+                        "tflops": round(2.0 * M * N * K / (sum(v) / len(v) * 1e-3) / 1e12, 1)}
+                       for (M, N, K), v in sorted(by_shape.items())]}
 
 
 def pmc_traffic(kernel):
@@ -289,6 +312,7 @@ def main():
     # to ONE stream here: on two, the attention kernels of the other stream share the CUs with the probed GEMM and the
     # events would time that mix, not the kernel.
     probe = {"epilogue": _lib.EPI_BIAS_GELU_TANH if cfg["bias_gelu_fusion"] else _lib.EPI_BIAS_GELU_ERF, "events": []}
+    probe["epilogues"] = {probe["epilogue"], _lib.EPI_NONE}  # + every plain GEMM: the N = h class (roofline_by_time)
     if rank == 0:
         ops.GEMM_EVENT_PROBE = probe
     streams_env = os.environ.get("MM_BRANCH_STREAMS")
@@ -336,6 +360,7 @@ def main():
                       ("eager launches" + ((" (%s)" if a.tp > 1 else " (graph capture failed: %s)") % graph_err if graph_err else "")),
             "eager_ms_per_step": round(dt_eager / a.steps * 1e3, 3),
             "roofline": roof,
+            "roofline_by_time": roofline_by_time(probe),
         }
         if a.layers:
             out["rehearsal"] = "num_layers overridden to %d: NOT a valid bench number" % a.layers

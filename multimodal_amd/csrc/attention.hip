@@ -183,9 +183,15 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
     }
 
     const int blk_last = min(q0 + 127, s - 1);
+#if defined(MM_AB_FWD_DBG) && (MM_AB_FWD_DBG & 8)  // decomposition build: every block walks the AVERAGE number of tiles, unmasked
+    const int ntiles = (s / 128 + 1);
+    const int wave_last = s - 1;
+    const int wave_first = s;
+#else
     const int ntiles = (MODE == 0) ? (blk_last / 64 + 1) : ((s + 63) / 64);
     const int wave_last = min(q0 + wave * 32 + 31, s - 1);
     const int wave_first = q0 + wave * 32;
+#endif
     const float mask_raw = kMaskFill * kLog2e / scale_log2e;  // raw score whose scaled value is -10000
     const uint8_t* mrow = nullptr;
     if (MODE == 1) mrow = mask + ((size_t)(mask_batches == 1 ? 0 : bi) * s + qrow_c) * s;
@@ -679,6 +685,13 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_k(u16* _
             load_stats((j + 1) * 64);
         }
         const int q0t = j * 64;
+        // (Round 3 experiment, measured and removed: for full tiles the two 32-query halves software-pipelined inside the wave - the
+        // S / dP MFMAs of half 1 issued between the softmax / dS arithmetic of half 0, the dV / dK MFMAs of half 0 between the
+        // arithmetic of half 1, order pinned with sched_group_barrier; 236 VGPRs, same two waves per SIMD, bit-identical results:
+        // dq + dkv 153 -> 159 us.  tools/ubench/coissue2.hip shows one wave CAN overlap the two pipes (16 MFMAs + 128 v_fma in
+        // 801 cycles against 520 + 731 apart) - with register operands.  Here every MFMA's A operand is an LDS read that hipcc
+        // places just ahead of its use, so the interleaved stream stops at an s_waitcnt lgkmcnt in front of each MFMA and each
+        // statistics load, and an in-order wave that waits there issues nothing on either pipe.)
         if (MODE == 1 || q0t + 63 >= wave_first) {  // some query of the tile can see a key of this wave
 #pragma unroll
             for (int t = 0; t < 2; ++t) {

@@ -289,7 +289,7 @@ def gptj_combine(x, attn, attn_bias, mlp, mlp_bias):
 
 # ---------------------------------------------------------------------------- GEMM
 GEMM_SPLITK = True        # plain GEMMs of split-K shapes go to mm_gemm_nt_splitk (False: always mm_gemm_nt; A/B tools flip it)
-GEMM_EVENT_PROBE = None  # set by bench.py to {"epilogue": code, "events": []} to time one kernel instantiation in situ
+GEMM_EVENT_PROBE = None  # set by bench.py to {"epilogues": {codes}, "events": []} to time kernel instantiations in situ
 
 
 def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, want_aux=False):
@@ -323,7 +323,7 @@ def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, wa
         aux = torch.empty(M, N, dtype=a.dtype, device=a.device)
     if residual is not None:
         residual = residual.contiguous()
-    probe = GEMM_EVENT_PROBE if (GEMM_EVENT_PROBE is not None and GEMM_EVENT_PROBE["epilogue"] == epilogue) else None
+    probe = GEMM_EVENT_PROBE if (GEMM_EVENT_PROBE is not None and epilogue in GEMM_EVENT_PROBE["epilogues"]) else None
     if probe is not None:  # bench.py: HIP events around this kernel, on the stream it is launched on
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -331,7 +331,7 @@ def gemm_nt(a, b, bias=None, epilogue=_lib.EPI_NONE, residual=None, out=None, wa
                                K, K, N, epilogue, dtype_code(a.dtype), _stream()), "gemm_nt")
     if probe is not None:
         e1.record()
-        probe["events"].append((e0, e1, M, N, K))
+        probe["events"].append((e0, e1, M, N, K, epilogue))
     c = c.view(*a.shape[:-1], N)
     if aux is not None:
         return c, aux.view(*a.shape[:-1], N)

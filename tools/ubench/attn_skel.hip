@@ -1,0 +1,141 @@
+// Developer microbenchmark (round 3): the MFMA + LDS-read skeleton of one attention-forward tile (32 queries x 64 keys, head size 64)
+// per wave - 8 ds_read_b128 (K rows), 8 MFMA 32x32x16 (S, two chains of four), 16 v_cvt_pk (P), 16 ds_read_b64_tr_b16 (V transposed),
+// 8 MFMA (P.V, two chains of four) - in a loop without barriers or global loads, at 1, 2 or 3 workgroups (of 4 waves) per CU.
+// Prints shader cycles per tile per SIMD; 512 is the matrix-pipe floor.  FLAGS: 1 = K reads, 2 = V transposed reads, 4 = converts,
+// 8 = the MFMAs read their A operand from the LDS data (otherwise from constant registers), 16 = the tile's softmax arithmetic
+// (max chain, fma + exp + row sum of 32 scores per lane) between the two products, in the same wave - the real kernel's order.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 2) void k(float* out, long long* cyc, int ntile) {
+    __shared__ __attribute__((aligned(16))) char smem[32768];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 8192; i += 256) reinterpret_cast<float*>(smem)[i] = 0.001f * i;
+    __syncthreads();
+    f32x16 o0, o1;
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    bf16x8 q[4], ca;
+    for (int d = 0; d < 4; ++d)
+        for (int i = 0; i < 8; ++i) q[d][i] = (__bf16)(0.001f * (threadIdx.x + i + d));
+    for (int i = 0; i < 8; ++i) ca[i] = (__bf16)(0.002f * (threadIdx.x - i));
+    float mrun = -1e30f, lrun = 0.f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int t = 0; t < ntile; ++t) {
+        const char* ks = smem + (t & 1) * 16384;
+        const char* vs = ks + 8192;
+        f32x16 s0, s1;
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+        asm volatile("v_xor_b32 %0, %0, %1" : "+v"(*reinterpret_cast<unsigned*>(&q[0])) : "v"(t));  // S is not loop-invariant
+        bf16x8 kf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (FLAGS & 1) kf[i] = *reinterpret_cast<const bf16x8*>(ks + ((lane & 31) + 32 * (i >> 2)) * 128 + ((((i & 3) * 2 + (lane >> 5)) ^ (lane & 7)) << 4));
+            else kf[i] = ca;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16((FLAGS & 8) ? kf[d] : ca, q[d], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16((FLAGS & 8) ? kf[4 + d] : ca, q[d], s1, 0, 0, 0);
+        }
+        if (!(FLAGS & 8) && (FLAGS & 1)) {  // keep the reads alive
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(kf[i]));
+        }
+        if (FLAGS & 16) {  // the softmax arithmetic of the tile on the S accumulators: max chain, exchange, fma + exp + row sum
+            float m = fmaxf(s0[0], s0[1]);
+#pragma unroll
+            for (int i = 2; i < 16; i += 2) m = fmaxf(fmaxf(m, s0[i]), s0[i + 1]);
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) m = fmaxf(fmaxf(m, s1[i]), s1[i + 1]);
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])) * 0.18f;
+            m = fmaxf(m, mrun);
+            float lsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float e0 = __builtin_fmaf(s0[i], 0.18f, -m), e1 = __builtin_fmaf(s1[i], 0.18f, -m);
+                asm volatile("" : "+v"(e0)); asm volatile("" : "+v"(e1));
+                s0[i] = __builtin_amdgcn_exp2f(e0); s1[i] = __builtin_amdgcn_exp2f(e1);
+                lsum += s0[i]; asm volatile("" : "+v"(lsum));
+                lsum += s1[i]; asm volatile("" : "+v"(lsum));
+            }
+            lrun += lsum;
+            mrun = m;
+        }
+        bf16x8 pf[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x16& sv = g < 2 ? s0 : s1;
+            const int b = 8 * (g & 1);
+            if (FLAGS & 4) pf[g] = bf16x8{(__bf16)sv[b], (__bf16)sv[b + 1], (__bf16)sv[b + 2], (__bf16)sv[b + 3], (__bf16)sv[b + 4], (__bf16)sv[b + 5], (__bf16)sv[b + 6], (__bf16)sv[b + 7]};
+            else { pf[g] = ca; asm volatile("" :: "v"(sv[b])); }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                bf16x8 vf = ca;
+                if (FLAGS & 2) {
+                    const int row = 16 * g + 4 * (lane >> 5) + ((lane & 15) >> 2);
+                    const int col = 32 * d + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                    const char* pa = vs + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2;
+                    const char* pb = vs + (row + 8) * 128 + (((col >> 3) ^ ((row + 8) & 7)) << 4) + (col & 7) * 2;
+                    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+                    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+                    const s16x8 v = s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                    if (FLAGS & 8) __builtin_memcpy(&vf, &v, 16);
+                    else asm volatile("" :: "v"(v));
+                }
+                if (d == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o0, 0, 0, 0);
+                else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o1, 0, 0, 0);
+            }
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float r = o0[0] + o1[5] + lrun + mrun;
+    if (r == 1234.5678f) out[threadIdx.x] = r;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int FLAGS> void run(const char* what, float* out, long long* cyc) {
+    const int ntile = 512;
+    printf("%-58s", what);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int w = 1; w <= 3; ++w) {
+        float ms = 0.f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL((k<FLAGS>), dim3(256 * w), dim3(256), 0, 0, out, cyc, ntile);
+            (void)hipEventRecord(e1, 0);
+            (void)hipDeviceSynchronize();
+            (void)hipEventElapsedTime(&ms, e0, e1);
+        }
+        long long h;
+        (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        // host view: the launch holds w tiles-streams per SIMD; ns per tile per SIMD = launch time / (ntile * w)
+        printf("  %d/SIMD: %5.0f cyc/tile/wave (block 0), launch %6.1f us = %5.1f ns/tile/SIMD", w, (double)h / ntile, ms * 1e3, ms * 1e6 / ntile / w);
+    }
+    printf("\n");
+}
+
+int main() {
+    float* out; long long* cyc;
+    (void)hipMalloc(&out, 4096); (void)hipMalloc(&cyc, 8);
+    run<0>("16 MFMAs, register operands", out, cyc);
+    run<4>("+ 16 converts of the S accumulators", out, cyc);
+    run<1>("+ 8 ds_read_b128 (not feeding the MFMAs)", out, cyc);
+    run<2>("+ 16 ds_read_b64_tr_b16 (not feeding the MFMAs)", out, cyc);
+    run<9>("K reads feeding the S MFMAs", out, cyc);
+    run<10>("V reads feeding the P.V MFMAs", out, cyc);
+    run<15>("everything (the forward tile without softmax)", out, cyc);
+    run<20>("16 MFMAs (register operands) + converts + softmax arithmetic", out, cyc);
+    run<31>("the forward tile with softmax arithmetic", out, cyc);
+    return 0;
+}
