@@ -6,7 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_amd import harness, mpu
 dev = torch.device("cuda", 0)
 mpu.initialize_model_parallel(1); mpu.model_parallel_cuda_manual_seed(1234)
-cfg = harness.CONFIGS["magma_pythia_410M"]
+# usage: cpu_overhead.py [config [layers]] - e.g. "6-7B 8": the per-layer enqueue cost of a wide config without building all of it
+cfg = dict(harness.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "magma_pythia_410M"])
+if len(sys.argv) > 2:
+    cfg["num_layers"] = int(sys.argv[2])
+print("config %s, %d layers, h=%d" % (sys.argv[1] if len(sys.argv) > 1 else "magma_pythia_410M", cfg["num_layers"], cfg["hidden_size"]))
 model = harness.MagmaStack(cfg, dtype=torch.bfloat16, device=dev); model.train()
 params = model.trainable_parameters()
 opt = torch.optim.Adam(params, lr=8e-4, fused=True)

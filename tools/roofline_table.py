@@ -17,13 +17,15 @@ ROWS = [
     ("gemm_nt_pp_k<mm::BF16, 2, false, 256", "h->4h GEMM + bias-GeLU (saves pre-activation), ping-pong 256x256", "mfma", 2.0 * T * 4 * H * H, ""),
     ("gemm_nt_pp_k<mm::BF16, 6, true, 256", "4h->h data-gradient GEMM + GeLU', ping-pong 256x256", "mfma", 2.0 * T * 4 * H * H, ""),
     ("gemm_nt_pp_k<mm::BF16, 8, false, 256", "QKV GEMM + bias + rotary, ping-pong 256x256", "mfma", 2.0 * T * 3 * H * H, ""),
-    ("gemm_nt_pp_k<mm::BF16, 0, false, 256", "LM head GEMM, ping-pong 256x256", "mfma", 2.0 * T * V * H, ""),
+    ("gemm_nt_pp_k<mm::BF16, 0, false, 256, 0, 1>", "LM head GEMM, ping-pong 256x256", "mfma", 2.0 * T * V * H, ""),
+    ("gemm_nt_pp_k<mm::BF16, 0, false, 256, 0, 2>", "LM head data gradient (N = h, K = V), ping-pong 256x256 with in-kernel split-K", "mfma",
+     2.0 * T * V * H, "round 3; was on gemm_nt_128_k"),
     ("gemm_nt_256_k<mm::BF16, 2, false>", "h->4h GEMM + bias-GeLU (saves pre-activation)", "mfma", 2.0 * T * 4 * H * H, ""),
     ("gemm_nt_256_k<mm::BF16, 6, true>", "4h->h data-gradient GEMM + GeLU'", "mfma", 2.0 * T * 4 * H * H, ""),
     ("gemm_nt_128_k<mm::BF16, 8, false>", "QKV GEMM + bias + rotary", "mfma", 2.0 * T * 3 * H * H, ""),
     ("gemm_nt_256_k<mm::BF16, 0, false>", "LM head GEMM", "mfma", 2.0 * T * V * H, ""),
     ("gemm_nt_128_k<mm::BF16, 0, false>", "N = h GEMMs (dense, 4h->h, and the dgrads of QKV / dense / h->4h / head)", "mfma",
-     (24 * 2.0 * T * H * (H + 4 * H + 3 * H + H + 4 * H) + 2.0 * T * V * H) / (24 * 5 + 1), "launch-weighted mean of 6 shapes"),
+     (24 * 2.0 * T * H * (H + 4 * H + 3 * H + H + 4 * H)) / (24 * 5), "launch-weighted mean of 3 shapes, K = 1024 (x2), 3072, 4096 (x2)"),
     ("attn_fwd_k<mm::BF16, 64, 0", "attention forward", "mfma", attn_f, "full s x s convention (causal-exact is half)"),
     ("attn_bwd_dkv_k<mm::BF16, 64, 0", "attention backward dK, dV (+ rotary backward on dK)", "mfma", attn_f * 2.0, "4 of 5 products; convention as above"),
     ("attn_bwd_dq_k<mm::BF16, 64, 0", "attention backward dQ (+ rotary backward)", "mfma", attn_f * 1.5, "3 products (S and dP recomputed)"),
