@@ -267,6 +267,14 @@ def load_checkpoint(model, load_dir, iteration=None, strict=False, finetune=Fals
             opt_loaded = True
         else:
             optimizer.refresh_master_from_params()
+            if not finetune:
+                # resuming (not fine-tuning) without this library's optimizer file: the Adam moments and step count start
+                # from zero.  The reference restores them from its DeepSpeed ZeRO files (megatron/checkpointing.py:231-242),
+                # whose format only the DeepSpeed engine reads - parity unpinned, so say so loudly instead of silently resetting.
+                warnings.warn("load_checkpoint: no optimizer state restored from %s (%s); Adam moments and step restart from zero, "
+                              "fp32 master weights were refreshed from the loaded parameters"
+                              % (ckpt_dir, "tensor-parallel degree differs: %d -> %d" % (parts, world) if parts != world
+                                 else "no %s" % os.path.basename(of)))
     return int(it), dict(missing=missing, unexpected=unexpected, client_state=client, tag=tag, optimizer_state_loaded=opt_loaded)
 
 
