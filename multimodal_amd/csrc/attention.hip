@@ -74,6 +74,16 @@ __device__ __forceinline__ void half_pair(float x, float& lo, float& hi) {
     lo = __uint_as_float(r[0]);
     hi = __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float half_max(float x) {
     float lo, hi;
     half_pair(x, lo, hi);
@@ -216,8 +226,12 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
 #define MM_AB_FWD_DBG 0  // store in the loop, 4 = no softmax arithmetic (P = S)
 #endif
     constexpr int DBG = MM_AB_FWD_DBG;
-    for (int j = 0; j < ntiles; ++j) {
-        const int cur = j & 1;
+    // The ring stage is a compile-time constant of each copy of the tile body (the loop walks two tiles per trip): every LDS
+    // address is then a loop-invariant per-lane register plus an immediate, where a run-time stage costs 17 v_add_u32 per tile
+    // and wave in a loop that the vector port bounds (in-kernel clock 1.98 GHz: 1350 cycles per tile and SIMD for ~1000 cycles of
+    // vector + MFMA issue, section 11 of DESIGN.md).
+    auto tile_step = [&](const int j, auto parity) {
+        constexpr int cur = decltype(parity)::value;
         const char* ks = smem + cur * 2 * TL::BYTES;
         const char* vs = ks + TL::BYTES;
         if (!(DBG & 2) && j + 1 < ntiles) {
@@ -288,13 +302,20 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
                     for (int i = 0; i < 16; ++i)
                         if (kv0 + 32 * t + acc_row(i, hh) > qrow) sacc[t][i] = -INFINITY;
             }
-            float rmax = sacc[0][0];
+            // v_max3_f32 by hand: fmaxf on MFMA outputs makes the compiler canonicalise every operand first (8 extra v_max per tile)
+            float rmax = vmax3(sacc[0][0], sacc[0][1], sacc[0][2]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int i = 3; i < 15; i += 2) rmax = vmax3(rmax, sacc[0][i], sacc[0][i + 1]);
+            rmax = vmax3(rmax, sacc[0][15], sacc[1][0]);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) rmax = fmaxf(rmax, sacc[t][i]);
-            rmax = half_max(rmax);
-            const float m_new = fmaxf(m_run, rmax * scale_log2e);
+            for (int i = 1; i < 15; i += 2) rmax = vmax3(rmax, sacc[1][i], sacc[1][i + 1]);
+            rmax = vmax2(rmax, sacc[1][15]);
+            {
+                float lo, hi;
+                half_pair(rmax, lo, hi);
+                rmax = vmax2(lo, hi);
+            }
+            const float m_new = vmax2(rmax * scale_log2e, m_run);
             // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU issue
             const f32x2 sc2 = {scale_log2e, scale_log2e}, mn2 = {m_new, m_new};
             f32x2 lsum2 = {0.f, 0.f};
@@ -351,6 +372,10 @@ __global__ __launch_bounds__(256, (HD == 64 ? 2 : 1)) void attn_fwd_k(u16* __res
             tile_store<HD>(nk + TL::BYTES, vreg, tid);
         }
         if (!(DBG & 1)) __syncthreads();
+    };
+    for (int j = 0; j < ntiles; j += 2) {
+        tile_step(j, std::integral_constant<int, 0>{});
+        if (j + 1 < ntiles) tile_step(j + 1, std::integral_constant<int, 1>{});
     }
 
     const float l_tot = half_sum(l_run);

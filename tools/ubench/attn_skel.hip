@@ -57,6 +57,20 @@ __global__ __launch_bounds__(256, 2) void k(float* out, long long* cyc, int ntil
             m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])) * 0.18f;
             m = fmaxf(m, mrun);
             float lsum = 0.f;
+            if (FLAGS & 32) {  // the kernel's packed form: v_pk_fma_f32 / v_pk_add_f32 on score pairs
+                typedef __attribute__((ext_vector_type(2))) float f32x2;
+                const f32x2 sc2 = {0.18f, 0.18f}, mn2 = {m, m};
+                f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 e0 = f32x2{s0[i], s0[i + 1]} * sc2 - mn2, e1 = f32x2{s1[i], s1[i + 1]} * sc2 - mn2;
+                    const f32x2 p0 = {__builtin_amdgcn_exp2f(e0[0]), __builtin_amdgcn_exp2f(e0[1])};
+                    const f32x2 p1 = {__builtin_amdgcn_exp2f(e1[0]), __builtin_amdgcn_exp2f(e1[1])};
+                    s0[i] = p0[0]; s0[i + 1] = p0[1]; s1[i] = p1[0]; s1[i + 1] = p1[1];
+                    ls2 += p0; ls2 += p1;
+                }
+                lsum = ls2[0] + ls2[1];
+            } else
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float e0 = __builtin_fmaf(s0[i], 0.18f, -m), e1 = __builtin_fmaf(s1[i], 0.18f, -m);
@@ -137,5 +151,6 @@ int main() {
     run<15>("everything (the forward tile without softmax)", out, cyc);
     run<20>("16 MFMAs (register operands) + converts + softmax arithmetic", out, cyc);
     run<31>("the forward tile with softmax arithmetic", out, cyc);
+    run<63>("the same with packed fp32 (v_pk_fma / v_pk_add) arithmetic", out, cyc);
     return 0;
 }
