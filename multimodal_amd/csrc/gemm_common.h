@@ -225,7 +225,9 @@ __device__ __forceinline__ void epilogue_rotary_pass(char* wl, int m_base, int n
 // activation's derivative to the rounded product, i.e. they are the data-gradient GEMM + the elementwise backward kernel.
 // Rounding order is the reference's eager order (product rounded, + bias rounded, activation, + residual rounded).  `wl` must not be shared with another wave; all
 // LDS traffic of the K loop must have completed for every wave (barrier) before the call.
-template <typename T, int EPI, bool RES, int MI>
+// MI0 / MIC: stage and store only the 16-row blocks MI0 .. MI0 + MIC - 1 of the accumulator (m_base = the first row of THAT part; the
+// staged image is MIC*16 rows), for callers whose staging area is smaller than the wave's whole tile.
+template <typename T, int EPI, bool RES, int MI, int MI0 = 0, int MIC = MI>
 __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char* wl, int m_base, int n_base, int M, int N, int ldc,
                                                 u16* __restrict__ C, u16* __restrict__ aux, const u16* __restrict__ bias,
                                                 const u16* __restrict__ Rsd, int lane, const EpiExtra& ex = EpiExtra{}) {
@@ -237,12 +239,12 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if ((EPI == MM_EPI_BIAS || EPI == MM_EPI_BIAS_RELU || EPI == MM_EPI_BIAS_ROTARY) && n0 < N) load_bias4<T>(bv, bias, n0);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
+        for (int mi = 0; mi < MIC; ++mi) {
             const int row = mi * 16 + frow;
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o[j] = acc[ni][mi][j];
+                o[j] = acc[ni][MI0 + mi][j];
                 if (EPI == MM_EPI_BIAS || EPI == MM_EPI_BIAS_ROTARY) o[j] += bv[j];
                 if (EPI == MM_EPI_BIAS_RELU) o[j] = fmaxf(rnd<T>(o[j] + bv[j]), 0.f);
             }
@@ -251,14 +253,14 @@ __device__ __forceinline__ void epilogue_staged(const f32x4 (&acc)[4][MI], char*
                 u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
         }
     }
-    if constexpr (EPI == MM_EPI_BIAS_ROTARY) epilogue_rotary_pass<T, MI>(wl, m_base, n_base, M, aux, Rsd, ex, lane);
+    if constexpr (EPI == MM_EPI_BIAS_ROTARY) epilogue_rotary_pass<T, MIC>(wl, m_base, n_base, M, aux, Rsd, ex, lane);
     const int c = lane & 7, n = n_base + c * 8;
     // interior tiles (all of M = 8192-class problems) take a predicate-free copy of phase 2: no exec-mask branches, so the
     // compiler batches the LDS reads / residual loads of several row groups ahead of the math
-    if (m_base + MI * 16 <= M && n_base + 64 <= N)
-        epilogue_phase2<T, EPI, RES, MI, true>(wl, m_base, n, M, N, ldc, C, aux, bias, Rsd, lane);
+    if (m_base + MIC * 16 <= M && n_base + 64 <= N)
+        epilogue_phase2<T, EPI, RES, MIC, true>(wl, m_base, n, M, N, ldc, C, aux, bias, Rsd, lane);
     else
-        epilogue_phase2<T, EPI, RES, MI, false>(wl, m_base, n, M, N, ldc, C, aux, bias, Rsd, lane);
+        epilogue_phase2<T, EPI, RES, MIC, false>(wl, m_base, n, M, N, ldc, C, aux, bias, Rsd, lane);
 }
 
 // gemm256.hip: returns MM_OK when it ran the problem, 1 when the shape is not one it takes (caller falls back), <0 on error.

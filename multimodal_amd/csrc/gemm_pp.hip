@@ -85,30 +85,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
     int tm, tn;
     // split-K: blocks b and b + 8 (b & 8 == 0) are the two K-slices of tile (b & 7) + 8 * (b >> 4)
     const int slice = SPLITK == 2 ? (int)((blockIdx.x >> 3) & 1) : 0;
-    const int tidx = SPLITK == 2 ? (int)((blockIdx.x & 7) | ((blockIdx.x >> 4) << 3)) : (int)blockIdx.x;
+    // SPLITK == 1 is PERSISTENT: the launch is at most one workgroup per CU (256, a multiple of 8, so all tiles of a workgroup fall
+    // into the same XCD run of tile_coords) and workgroup b walks tiles b, b + gridDim.x, ...  Between two tiles it fetches the next
+    // tile's first K-tile into stage 0 BEFORE its epilogue, which stages through stage 1 only (two passes of half the wave tile).
+    int tidx = SPLITK == 2 ? (int)((blockIdx.x & 7) | ((blockIdx.x >> 4) << 3)) : (int)blockIdx.x;
     tile_coords(tidx, tiles_m, tiles_n, group_m, tm, tn);
-    const int bm = tm * P::BM, bn = tn * BN;
+    int bm = tm * P::BM, bn = tn * BN;
     const int wr = wave / P::WAVES_N, wc = wave % P::WAVES_N;
     const int frow = lane & 15, fq = lane >> 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
 
     // ---- global -> LDS staging: instruction i of a tile covers rows i*64 + wave*8 + (lane>>3), LDS chunk lane&7
     uint32_t goffA[P::NLA], goffB[P::NLB];
-    {
+    auto set_tile = [&](int bm_, int bn_) {
         const int rl = wave * 8 + (lane >> 3), cl = lane & 7;
 #pragma unroll
         for (int i = 0; i < P::NLA; ++i) {
             const int r = i * 64 + rl;
-            const int gr = min(bm + r, M - 1);  // edge tiles re-read the last row (never stored)
+            const int gr = min(bm_ + r, M - 1);  // edge tiles re-read the last row (never stored)
             goffA[i] = (uint32_t)gr * (uint32_t)(lda * 2) + (uint32_t)((cl ^ ((r >> 1) & 7)) << 4);
         }
 #pragma unroll
         for (int i = 0; i < P::NLB; ++i) {
             const int r = i * 64 + rl;
-            const int gr = min(bn + r, N - 1);
+            const int gr = min(bn_ + r, N - 1);
             goffB[i] = (uint32_t)gr * (uint32_t)(ldb * 2) + (uint32_t)((cl ^ ((r >> 1) & 7)) << 4);
         }
-    }
+    };
+    set_tile(bm, bn);
     const int nt = (K / 64) / SPLITK;     // K-tiles of this workgroup: slice * nt .. slice * nt + nt - 1
     auto issue = [&](int t, int stage) {  // this wave's rows of K-tile t
         const char* ag = (const char*)A + (size_t)(slice * nt + t) * P::ROWB;
@@ -144,10 +148,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
     };
 
     f32x4 acc[4][MI];  // [ni][mi]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&]() {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -172,6 +172,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
 #endif
     // ---- prologue: tiles 0 and 1 by everyone; tile 0 visible after the barrier
     issue(0, 0);
+    for (;;) {  // one output tile per trip
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nt > 1) {
         issue(1, 1);
         PP_WAIT(P::NL, 15);
@@ -268,8 +273,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
     }
     // ---- epilogue (coalesced through a wave-private LDS region: MI*16 rows x 128 B).  Group 0 starts it one phase before
     // group 1, whose last phase computes from registers; nobody touches the stages any more.
-    epilogue_staged<T, EPI, RES, MI>(acc, smem + wave * (MI * 16 * 128), bm + wr * P::WM, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd,
-                                     lane, ex);
+    if constexpr (SPLITK == 2) {
+        epilogue_staged<T, EPI, RES, MI>(acc, smem + wave * (MI * 16 * 128), bm + wr * P::WM, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd,
+                                         lane, ex);
+        return;
+    } else {
+        // the next tile of this workgroup: its K-tile 0 goes into stage 0 now (every wave is past its last fragment read: the barrier
+        // that ended the last load phase), and lands while the epilogue runs in stage 1
+        tidx += (int)gridDim.x;
+        const bool more = tidx < tiles_m * tiles_n;
+        int nbm = 0, nbn = 0;
+        if (more) {
+            tile_coords(tidx, tiles_m, tiles_n, group_m, tm, tn);
+            nbm = tm * P::BM, nbn = tn * BN;
+            set_tile(nbm, nbn);
+            issue(0, 0);
+        }
+        constexpr int MH = MI / 2;
+        static_assert(8 * MH * 16 * 128 <= P::STAGE, "the two-pass epilogue stages inside stage 1");
+        // the epilogue's per-lane addressing is derived from an opaque copy of the thread id: otherwise the compiler hoists it out of
+        // the tile loop, keeps it live across the K loop and spills
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        const int wave_e = tid_e >> 6, lane_e = tid_e & 63;
+        const int wr_e = wave_e / P::WAVES_N, wc_e = wave_e % P::WAVES_N;
+        char* wl = smem + P::STAGE + wave_e * (MH * 16 * 128);
+        epilogue_staged<T, EPI, RES, MI, 0, MH>(acc, wl, bm + wr_e * P::WM, bn + wc_e * 64, M, N, ldc, C, aux, bias, Rsd, lane_e, ex);
+        epilogue_staged<T, EPI, RES, MI, MH, MH>(acc, wl, bm + wr_e * P::WM + MH * 16, bn + wc_e * 64, M, N, ldc, C, aux, bias, Rsd, lane_e,
+                                                 ex);
+        if (!more) return;
+        bm = nbm, bn = nbn;
+        __syncthreads();  // every wave's staging reads are done: stage 1 takes K-tile 1 of the next tile
+    }
+    }
 }
 
 template <typename T, int EPI, int BN>
@@ -280,7 +316,7 @@ static int launch_pp(void* C, void* aux, const void* A, const void* B, const voi
     const int nwg = tiles_m * tiles_n;
     int group_m = (nwg / 8) / tiles_n;  // one XCD's run of tiles spans whole tile-rows when it can
     group_m = group_m < 1 ? 1 : (group_m > 8 ? 8 : group_m);
-    dim3 grid(nwg), block(512);
+    dim3 grid(nwg > 256 ? 256 : nwg), block(512);  // persistent: at most one workgroup per CU, each walks its tiles
     // (the rotary epilogue carries its tables in the aux / residual slots: never a residual add)
     if (EPI != MM_EPI_BIAS_ROTARY && (epi_is_bwd(EPI) || residual)) {
         if constexpr (EPI != MM_EPI_BIAS_ROTARY)
