@@ -8,8 +8,8 @@
 // global->LDS issue (8 LDS-DMA pieces, ~60-180 cycles of issue each), their 24 fragment reads and their 64 MFMAs at the same
 // time and take turns instead of overlapping.  Here the two waves of a SIMD run OPPOSITE phases:
 //
-//   waves 0-3 (group 0) | compute t   | load t+1   | compute t+1 | load t+2   | ...
-//   waves 4-7 (group 1) | load t      | compute t  | load t+1    | compute t+1| ...
+//   waves 0-3 (group 0) | compute t   | load       | compute t+1 | load       | ...
+//   waves 4-7 (group 1) | load        | compute t  | load        | compute t+1| ...
 //                       ^ one s_barrier per phase (two per 64-deep K-tile)
 //
 //   compute phase: the wave's 2*MI*4 MFMAs (16x16x32) of one K-tile, back to back, every operand already in registers;
@@ -18,10 +18,16 @@
 //   (A workgroup's waves go to the SIMDs in cyclic order, so every SIMD holds one wave of each group: in every phase each
 //    SIMD has exactly one wave issuing MFMAs and one wave issuing memory instructions.)
 //
-// Two 64-deep LDS stages (A 256 x 128 B, B BN x 128 B; lane-linear 8-row images, 16-byte chunk index XOR (row>>1)&7 on the
-// DMA source address and on the read address).  Tile T lives in stage T&1; its DMA is issued by group 0 in phase 2T-3 and by
-// group 1 in phase 2T-2, and first read in phase 2T-1: the stage was last read (tile T-2) in phases 2T-5 / 2T-4.  Every wave
-// drains its own DMA (vmcnt) before the barrier that precedes the first reader.  Hazard notes sit next to the code.
+// LDS (round 3): the A operand of a K-tile (256 x 128 B) and the B operand (BN x 128 B) live in SEPARATE rings - A in two
+// stages, B in three (BN = 256: 2 x 32 + 3 x 32 = 160 KiB, all of a CU's LDS).  Group 0's waves fetch all of A, group 1's all of
+// B.  With two whole-tile stages (round 2) group 1 could only fetch tile t+1 in the phase right before group 0 reads it, and
+// waited out the full fetch latency in that phase, every K-tile: measured with that wait removed (results wrong, timing only)
+// the K loop ran 18 % faster at K = 16384 and the bias-GeLU GEMM 6 %.  The third B stage lets group 1 fetch B of tile t+2 while
+// tile t is still being read; its wait covers the batch issued one K-tile earlier (counted vmcnt).  Hazard notes sit next to
+// the code.  Lane-linear 8-row images, 16-byte chunk index XOR (row>>1)&7 on the DMA source address and on the read address.
+//
+// Persistent (round 3): at most one workgroup per CU; workgroup b walks output tiles b, b + grid, ...  Before the epilogue of a
+// tile it issues K-tile 0 of its next tile (A stage 0, B stage 0); the epilogue stages through B stages 1-2 in two passes.
 //
 // BN = 256: waves 2(M) x 4(N), 128x64 per wave (the h->4h class and the LM head: >= 256 tiles).
 // BN = 128: waves 4(M) x 2(N),  64x64 per wave (the N = h class: M=8192, N=1024 is exactly 256 tiles = one per CU, where
@@ -33,11 +39,15 @@ namespace mm {
 template <int BN_> struct PP {
     static constexpr int BM = 256, BN = BN_;
     static constexpr int ROWB = 128;  // bytes per tile row (64 k-elements)
-    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
-    static constexpr int NLA = BM / 64, NLB = BN / 64, NL = NLA + NLB;  // LDS-DMA instructions per wave per K-tile
+    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    static constexpr int NSA = 2, NSB = 3;                               // ring depths
+    static constexpr int B_BASE = NSA * A_BYTES, LDS = B_BASE + NSB * B_BYTES;
+    static constexpr int NPA = BM / 32, NPB = BN / 32;                   // LDS-DMA instructions per wave and K-tile: group 0 (A), group 1 (B)
+    static constexpr int NPMAX = NPA > NPB ? NPA : NPB;
     static constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;
     static constexpr int WM = BM / WAVES_M, MI = WM / 16;               // wave tile WM x 64: MI x 4 accumulators
     static constexpr int NREADS = 2 * (MI + 4);                         // ds_read_b128 per wave per K-tile
+    static_assert(LDS <= 160 * 1024, "one workgroup per CU: at most the CU's 160 KiB");
 };
 
 constexpr int pp_waitcnt(int vm, int lgkm) { return (vm & 0xF) | (7 << 4) | ((lgkm & 0xF) << 8) | (((vm >> 4) & 3) << 14); }
@@ -80,14 +90,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
     constexpr int MI = P::MI;
     typedef typename Mfma<T>::frag frag;
     static_assert(SPLITK == 1 || (SPLITK == 2 && BN == 256), "split-K: two slices of a 256 x 256 tile");
-    __shared__ __attribute__((aligned(16))) char smem[P::LDS + 8 * 256];  // the ONLY LDS object of the kernel (+ the warming loads' dump area)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ __attribute__((aligned(16))) char smem[P::LDS];  // the ONLY LDS object of the kernel
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index as a SCALAR: everything derived from it (LDS-DMA bases in M0, group tests) stays in SGPRs.  As a vector value it
+    // was spilled under the epilogue's register pressure and re-loaded inside the K loop - and a scratch reload waits vmcnt(0),
+    // i.e. for every DMA in flight, once per phase.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool g0 = wave < 4;  // group 0: waves 0-3
+    const int w4 = wave & 3;
     int tm, tn;
     // split-K: blocks b and b + 8 (b & 8 == 0) are the two K-slices of tile (b & 7) + 8 * (b >> 4)
     const int slice = SPLITK == 2 ? (int)((blockIdx.x >> 3) & 1) : 0;
     // SPLITK == 1 is PERSISTENT: the launch is at most one workgroup per CU (256, a multiple of 8, so all tiles of a workgroup fall
-    // into the same XCD run of tile_coords) and workgroup b walks tiles b, b + gridDim.x, ...  Between two tiles it fetches the next
-    // tile's first K-tile into stage 0 BEFORE its epilogue, which stages through stage 1 only (two passes of half the wave tile).
+    // into the same XCD run of tile_coords) and workgroup b walks tiles b, b + gridDim.x, ...
     int tidx = SPLITK == 2 ? (int)((blockIdx.x & 7) | ((blockIdx.x >> 4) << 3)) : (int)blockIdx.x;
     tile_coords(tidx, tiles_m, tiles_n, group_m, tm, tn);
     int bm = tm * P::BM, bn = tn * BN;
@@ -95,50 +110,49 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
     const int frow = lane & 15, fq = lane >> 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
 
-    // ---- global -> LDS staging: instruction i of a tile covers rows i*64 + wave*8 + (lane>>3), LDS chunk lane&7
-    uint32_t goffA[P::NLA], goffB[P::NLB];
+    // ---- global -> LDS staging.  A wave of group 0 fills rows i*32 + w4*8 + (lane>>3) of the A image with its instruction i
+    // (i < NPA), a wave of group 1 the same rows of the B image (i < NPB); lane & 7 is the 16-byte LDS chunk.
+    uint32_t goff[P::NPMAX];
     auto set_tile = [&](int bm_, int bn_) {
-        const int rl = wave * 8 + (lane >> 3), cl = lane & 7;
+        const int rl = w4 * 8 + (lane >> 3), cl = lane & 7;
+        const int base = g0 ? bm_ : bn_, lim = g0 ? M : N;
+        const uint32_t ldbytes = (uint32_t)((g0 ? lda : ldb) * 2);
 #pragma unroll
-        for (int i = 0; i < P::NLA; ++i) {
-            const int r = i * 64 + rl;
-            const int gr = min(bm_ + r, M - 1);  // edge tiles re-read the last row (never stored)
-            goffA[i] = (uint32_t)gr * (uint32_t)(lda * 2) + (uint32_t)((cl ^ ((r >> 1) & 7)) << 4);
-        }
-#pragma unroll
-        for (int i = 0; i < P::NLB; ++i) {
-            const int r = i * 64 + rl;
-            const int gr = min(bn_ + r, N - 1);
-            goffB[i] = (uint32_t)gr * (uint32_t)(ldb * 2) + (uint32_t)((cl ^ ((r >> 1) & 7)) << 4);
+        for (int i = 0; i < P::NPMAX; ++i) {
+            const int r = i * 32 + rl;
+            const int gr = min(base + r, lim - 1);  // edge tiles re-read the last row (never stored)
+            goff[i] = (uint32_t)gr * ldbytes + (uint32_t)((cl ^ ((r >> 1) & 7)) << 4);
         }
     };
     set_tile(bm, bn);
     const int nt = (K / 64) / SPLITK;     // K-tiles of this workgroup: slice * nt .. slice * nt + nt - 1
-    auto issue = [&](int t, int stage) {  // this wave's rows of K-tile t
-        const char* ag = (const char*)A + (size_t)(slice * nt + t) * P::ROWB;
-        const char* bg = (const char*)B + (size_t)(slice * nt + t) * P::ROWB;
-        char* la = smem + stage * P::STAGE + wave * 8 * P::ROWB;  // wave-uniform; HW adds lane*16
-        char* lb = la + P::A_BYTES;
+    auto issue_a = [&](int t, int stage) {  // group 0: this wave's rows of the A operand of K-tile t
+        const char* g = (const char*)A + (size_t)(slice * nt + t) * P::ROWB;
+        char* l = smem + stage * P::A_BYTES + w4 * 8 * P::ROWB;  // wave-uniform; HW adds lane*16
 #pragma unroll
-        for (int i = 0; i < P::NLA; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(ag + goffA[i]), (lds_void*)(la + i * 64 * P::ROWB), 16, 0, 0);
+        for (int i = 0; i < P::NPA; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(g + goff[i]), (lds_void*)(l + i * 32 * P::ROWB), 16, 0, 0);
+    };
+    auto issue_b = [&](int t, int stage) {  // group 1: this wave's rows of the B operand of K-tile t
+        const char* g = (const char*)B + (size_t)(slice * nt + t) * P::ROWB;
+        char* l = smem + P::B_BASE + stage * P::B_BYTES + w4 * 8 * P::ROWB;
 #pragma unroll
-        for (int i = 0; i < P::NLB; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(bg + goffB[i]), (lds_void*)(lb + i * 64 * P::ROWB), 16, 0, 0);
+        for (int i = 0; i < P::NPB; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(g + goff[i]), (lds_void*)(l + i * 32 * P::ROWB), 16, 0, 0);
     };
 
     // ---- fragment reads: byte address row*128 + ((k-chunk) ^ ((row>>1)&7))*16; steps of 16 rows keep the swizzle term, so they
     // are immediate offsets of the ds_read
     const uint32_t sw = (uint32_t)((frow >> 1) & 7);
     const uint32_t arow = (uint32_t)((wr * P::WM + frow) * P::ROWB);
-    const uint32_t brow = (uint32_t)(P::A_BYTES + (wc * 64 + frow) * P::ROWB);
+    const uint32_t brow = (uint32_t)(P::B_BASE + (wc * 64 + frow) * P::ROWB);
     u32x4 fa[2][MI], fb[2][4];  // [k-half][16-row block]: the whole K-tile's operands of this wave
-    auto read_frags = [&](int stage) {
+    auto read_frags = [&](int sa, int sb) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const uint32_t ch = ((((uint32_t)(kk * 4 + fq)) ^ sw) << 4);
-            const uint32_t ba = lds0 + stage * P::STAGE + brow + ch;
-            const uint32_t aa = lds0 + stage * P::STAGE + arow + ch;
+            const uint32_t ba = lds0 + sb * P::B_BYTES + brow + ch;
+            const uint32_t aa = lds0 + sa * P::A_BYTES + arow + ch;
             fb[kk][0] = pp_lds_read16<0 * 2048>(ba);
             fb[kk][1] = pp_lds_read16<1 * 2048>(ba);
             fb[kk][2] = pp_lds_read16<2 * 2048>(ba);
@@ -159,59 +173,82 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
                     acc[ni][mi] = Mfma<T>::run(__builtin_bit_cast(frag, fb[kk][ni]), __builtin_bit_cast(frag, fa[kk][mi]), acc[ni][mi]);
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto next3 = [](int s) { return s == 2 ? 0 : s + 1; };
 
-    // the weight matrix on its way into the Infinity Cache (first 256 workgroups of the launch; gemm_common.h)
-    touch_weight(B, N, K, ldb, blockIdx.x, min((int)gridDim.x, 256), tid, 512, smem + P::LDS + wave * 256);
+    // the weight matrix on its way into the Infinity Cache (first 256 workgroups of the launch; gemm_common.h).  Its dump area is
+    // B stage 2, first filled in phase 0: every wave has drained these loads by then (the prologue's counted wait is in issue order).
+    static_assert(8 * 256 <= P::B_BYTES, "dump area inside B stage 2");
+    touch_weight(B, N, K, ldb, blockIdx.x, min((int)gridDim.x, 256), tid, 512, smem + P::B_BASE + 2 * P::B_BYTES + wave * 256);
     // (Round 2 also warmed the backward epilogues' saved-tensor tile here, one dword per 128-byte line.  Round 3 A/B of exactly that,
     // same process, interleaved, everything cold - tools/ab_two_libs.py, M=8192 N=4096 K=1024 GeLU' epilogue: 95.2 us with the warming
     // loads, 87.8 without; whole step 20.13 -> 19.99 ms.  The 1024 scattered line fetches per workgroup delay its first K-tiles by
-    // more than the epilogue's streaming loads gain, and the counters showed the tensor fetched twice: 232 MiB against 88.  Removed;
-    // -DMM_AB_TOUCH_TILE brings it back for a variant build.)
-#ifdef MM_AB_TOUCH_TILE
-    if constexpr (BN == 256 && epi_is_bwd(EPI)) touch_tile256(Rsd, ldc, bm, bn, M, N, tid, smem + P::LDS + wave * 256);
-#endif
-    // ---- prologue: tiles 0 and 1 by everyone; tile 0 visible after the barrier
-    issue(0, 0);
+    // more than the epilogue's streaming loads gain, and the counters showed the tensor fetched twice: 232 MiB against 88.  Removed.)
+    // ---- prologue: K-tiles 0 and 1 (A by group 0, B by group 1); tile 0 visible after the barrier
+    if (g0) issue_a(0, 0); else issue_b(0, 0);
     for (;;) {  // one output tile per trip
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nt > 1) {
-        issue(1, 1);
-        PP_WAIT(P::NL, 15);
-    } else {
+    if (nt < 2) {
         PP_WAIT(0, 15);
+    } else if (g0) {
+        issue_a(1, 1);
+        PP_WAIT(P::NPA, 15);
+    } else {
+        issue_b(1, 1);
+        PP_WAIT(P::NPB, 15);
     }
     pp_barrier();
-    if (wave < 4) {
-        // ================= group 0: compute tile t in phase 2t, load in phase 2t+1
-        read_frags(0);
+    if (g0) {
+        // ================= group 0: compute tile t in phase 2t; in phase 2t+1 fetch A of tile t+2 and read tile t+1
+        read_frags(0, 0);
         PP_WAIT(63, 0);
+        int sb = 0;  // B stage of tile t
         for (int t = 0; t < nt; ++t) {
             compute();
-            // my DMA share of tile t+1 (issued in phase 2t-1, or in the prologue) has landed: the barrier publishes it
+            // A of tile t+1 (issued in phase 2t-1, or in the prologue) has landed: the barrier publishes it to group 1, which reads
+            // it in phase 2t+2
+#ifdef MM_AB_PP_T1  // timing only
+            PP_WAIT(P::NPA, 15);
+#else
             PP_WAIT(0, 15);
+#endif
             pp_barrier();                                   // end of phase 2t
             if (t + 1 >= nt) break;                         // nothing left to load: straight to the epilogue (LDS is free:
                                                             // group 1 finished its last fragment reads before this barrier)
-            if (!(DBG & 1)) if (t + 2 < nt) issue(t + 2, t & 1);            // stage t&1: tile t was last read in phase 2t (group 1), done
-            if (!(DBG & 2)) read_frags((t + 1) & 1);                        // tile t+1: both groups' DMA drained before the barrier above
+            sb = next3(sb);
+            if (!(DBG & 1)) if (t + 2 < nt) issue_a(t + 2, t & 1);          // A stage t&1: tile t was last read in phase 2t (group 1), done
+            if (!(DBG & 2)) read_frags((t + 1) & 1, sb);                    // tile t+1: its B was published by group 1's wait in phase 2t
             PP_WAIT(63, 0);                                 // fragments in registers; the DMA just issued stays in flight
             pp_barrier();                                   // end of phase 2t+1
         }
     } else {
-        // ================= group 1: load tile t in phase 2t, compute it in phase 2t+1
+        // ================= group 1: in phase 2t fetch B of tile t+2 and read tile t; compute it in phase 2t+1
+        int sbr = 0, sbi = 2;  // B stages of tile t and of tile t+2
         for (int t = 0; t < nt; ++t) {
-            if (!(DBG & 1)) if (t >= 1 && t + 1 < nt) issue(t + 1, (t + 1) & 1);  // stage of tile t-1: last read in phase 2t-2 (by this group)
-            if (!(DBG & 2) || t == 0) read_frags(t & 1);
-            PP_WAIT(0, 0);                                  // fragments in registers AND my DMA share of tile t+1 landed:
-            pp_barrier();                                   // end of phase 2t - group 0 reads tile t+1 right after it
+            // B stage of tile t+2 = that of tile t-1: last read in phase 2t-2 (this group) and 2t-3 (group 0)
+            const bool more = !(DBG & 1) && t + 2 < nt;
+            if (more) issue_b(t + 2, sbi);
+            if (!(DBG & 2) || t == 0) read_frags(t & 1, sbr);
+            // fragments in registers, and B of tile t+1 (issued one K-tile ago, or in the prologue) landed - group 0 reads it right
+            // after the barrier; the batch just issued stays in flight for two more phases
+#ifdef MM_AB_PP_T2  // timing only
+            PP_WAIT(2 * P::NPB, 0);
+#else
+            if (more) PP_WAIT(P::NPB, 0); else PP_WAIT(0, 0);
+#endif
+            pp_barrier();                                   // end of phase 2t
             compute();
             if (t + 1 < nt) pp_barrier();                   // end of phase 2t+1
+            sbr = next3(sbr), sbi = next3(sbi);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+#if defined(MM_AB_PP_T1) || defined(MM_AB_PP_T2)
+    PP_WAIT(0, 15);
+    __syncthreads();
+#endif
 
     if (DBG & 4) {  // keep the accumulators alive without storing anything real
         float sum = 0.f;
@@ -220,7 +257,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
 #pragma unroll
             for (int j = 0; j < MI; ++j) sum += acc[i][j][0] + acc[i][j][3];
         if (sum == 12345.678f) C[0] = (u16)lane;
-        return;
+        tidx += (int)gridDim.x;
+        if (tidx >= tiles_m * tiles_n) return;
+        tile_coords(tidx, tiles_m, tiles_n, group_m, tm, tn);
+        bm = tm * P::BM, bn = tn * BN;
+        set_tile(bm, bn);
+        if (g0) issue_a(0, 0); else issue_b(0, 0);
+        __syncthreads();
+        continue;
     }
     if constexpr (SPLITK == 2) {
         // ---- split-K exchange: wave row `slice` is finished here, wave row 1 - slice goes to the partner
@@ -239,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains before the barrier
         __syncthreads();
-        unsigned* lost = reinterpret_cast<unsigned*>(smem + P::LDS + 8 * 256 - 4);  // last word of the (now idle) dump area
+        unsigned* lost = reinterpret_cast<unsigned*>(smem + P::LDS - 4);  // last word of B stage 2: beyond the epilogue's staging area
         if (tid == 0) {
             __hip_atomic_store(sp.flags + tidx * 2 + (1 - slice), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0, gave_up = 0;
@@ -271,15 +315,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
                 for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{qnan, qnan, qnan, qnan};
         }
     }
-    // ---- epilogue (coalesced through a wave-private LDS region: MI*16 rows x 128 B).  Group 0 starts it one phase before
-    // group 1, whose last phase computes from registers; nobody touches the stages any more.
+    // ---- epilogue (coalesced through a wave-private LDS region).  Group 0 starts it one phase before group 1, whose last phase
+    // computes from registers; nobody reads the rings any more and every DMA into them has been waited for.
     if constexpr (SPLITK == 2) {
+        static_assert(SPLITK != 2 || 8 * MI * 16 * 128 <= P::LDS - 4, "split-K epilogue staging below the `lost` word");
         epilogue_staged<T, EPI, RES, MI>(acc, smem + wave * (MI * 16 * 128), bm + wr * P::WM, bn + wc * 64, M, N, ldc, C, aux, bias, Rsd,
                                          lane, ex);
         return;
     } else {
-        // the next tile of this workgroup: its K-tile 0 goes into stage 0 now (every wave is past its last fragment read: the barrier
-        // that ended the last load phase), and lands while the epilogue runs in stage 1
+        // the next tile of this workgroup: its K-tile 0 goes into A stage 0 / B stage 0 now and lands while the epilogue runs in
+        // B stages 1-2
         tidx += (int)gridDim.x;
         const bool more = tidx < tiles_m * tiles_n;
         int nbm = 0, nbn = 0;
@@ -287,23 +332,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
             tile_coords(tidx, tiles_m, tiles_n, group_m, tm, tn);
             nbm = tm * P::BM, nbn = tn * BN;
             set_tile(nbm, nbn);
-            issue(0, 0);
+            if (g0) issue_a(0, 0); else issue_b(0, 0);
         }
         constexpr int MH = MI / 2;
-        static_assert(8 * MH * 16 * 128 <= P::STAGE, "the two-pass epilogue stages inside stage 1");
+        static_assert(8 * MH * 16 * 128 <= 2 * P::B_BYTES, "the two-pass epilogue stages inside B stages 1-2");
         // the epilogue's per-lane addressing is derived from an opaque copy of the thread id: otherwise the compiler hoists it out of
         // the tile loop, keeps it live across the K loop and spills
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
         const int wave_e = tid_e >> 6, lane_e = tid_e & 63;
         const int wr_e = wave_e / P::WAVES_N, wc_e = wave_e % P::WAVES_N;
-        char* wl = smem + P::STAGE + wave_e * (MH * 16 * 128);
+        char* wl = smem + P::B_BASE + P::B_BYTES + wave_e * (MH * 16 * 128);
         epilogue_staged<T, EPI, RES, MI, 0, MH>(acc, wl, bm + wr_e * P::WM, bn + wc_e * 64, M, N, ldc, C, aux, bias, Rsd, lane_e, ex);
         epilogue_staged<T, EPI, RES, MI, MH, MH>(acc, wl, bm + wr_e * P::WM + MH * 16, bn + wc_e * 64, M, N, ldc, C, aux, bias, Rsd, lane_e,
                                                  ex);
         if (!more) return;
         bm = nbm, bn = nbn;
-        __syncthreads();  // every wave's staging reads are done: stage 1 takes K-tile 1 of the next tile
+        __syncthreads();  // every wave's staging reads are done: B stage 1 takes K-tile 1 of the next tile
     }
     }
 }
@@ -403,7 +448,7 @@ static void launch_pp_dbg(void* C, void* aux, const void* A, const void* B, cons
     const int nwg = tiles_m * tiles_n;
     int group_m = (nwg / 8) / tiles_n;
     group_m = group_m < 1 ? 1 : (group_m > 8 ? 8 : group_m);
-    gemm_nt_pp_k<BF16, EPI, false, 256, DBG><<<dim3(nwg), dim3(512), 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
+    gemm_nt_pp_k<BF16, EPI, false, 256, DBG><<<dim3(nwg > 256 ? 256 : nwg), dim3(512), 0, st>>>((u16*)C, (u16*)aux, (const u16*)A, (const u16*)B, (const u16*)bias,
                                                                             nullptr, M, N, K, K, K, N, tiles_m, tiles_n, group_m, EpiExtra{});
 }
 
