@@ -71,22 +71,25 @@ def roofline_from_probe(cfg, probe, tp=1):
             "traffic": pmc_traffic(label)}
 
 
-def roofline_by_time(probe):
-    """The kernel with the largest share of the step's time is not the roofline kernel above but `gemm_nt_128_k`, which takes every
-    plain N = h GEMM (attention dense, 4h->h, and the data gradients of QKV / dense / h->4h): the same in-situ HIP events, all of
-    its launches in the timed steps, launch-weighted (total FLOPs / total kernel time) and per shape."""
+def roofline_by_time(cfg, probe):
+    """The kernel class with the largest share of the step's time is not the roofline kernel above but the plain N = h GEMMs
+    (attention dense, 4h->h, and the data gradients of QKV / dense / h->4h; `gemm_nt_pp_k<128>`, 256 x 128 tiles, from round 3 on -
+    `gemm_nt_128_k` before): the same in-situ HIP events, all of its launches in the timed steps, launch-weighted (total FLOPs /
+    total kernel time) and per shape."""
     from multimodal_amd import ops, _lib
+    h = cfg["hidden_size"]
     by_shape = {}
     for e0, e1, M, N, K, epi in probe["events"]:
-        if epi != _lib.EPI_NONE or ops.gemm_nt_kernel_name(M, N, K, epi) != "gemm_nt_128_k":
+        if epi != _lib.EPI_NONE or N != h or K > 4 * h or K % 64:   # (K > 4h: the LM head's data gradient, a split-K launch of its own)
             continue
         by_shape.setdefault((M, N, K), []).append(e0.elapsed_time(e1))
     if not by_shape:
         return None
+    names = sorted({ops.gemm_nt_kernel_name(M, N, K, _lib.EPI_NONE) for (M, N, K) in by_shape})
     flops = sum(2.0 * M * N * K * len(v) for (M, N, K), v in by_shape.items())
     ms = sum(sum(v) for v in by_shape.values())
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_nt_128_k<bf16, plain> (the N = h class)", "achieved": round(achieved, 2),
+    return {"bound": "mfma", "kernel": "%s<bf16, plain> (the N = h class)" % " / ".join(names), "achieved": round(achieved, 2),
             "peak": PEAK_BF16_FLOPS / 1e12, "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_FLOPS / 1e12), 4),
             "launches_timed": sum(len(v) for v in by_shape.values()), "kernel_ms_total": round(ms, 3),
             "shapes": [{"M": M, "N": N, "K": K, "launches": len(v), "avg_kernel_ms": round(sum(v) / len(v), 4),
@@ -360,7 +363,7 @@ def main():
                       ("eager launches" + ((" (%s)" if a.tp > 1 else " (graph capture failed: %s)") % graph_err if graph_err else "")),
             "eager_ms_per_step": round(dt_eager / a.steps * 1e3, 3),
             "roofline": roof,
-            "roofline_by_time": roofline_by_time(probe),
+            "roofline_by_time": roofline_by_time(cfg, probe),
         }
         if a.layers:
             out["rehearsal"] = "num_layers overridden to %d: NOT a valid bench number" % a.layers

@@ -489,9 +489,15 @@ int gemm_pp_tile(int M, int N, int K, int lda, int ldb) {
     // Other widths (h = 512, 2304 / TP 2, 4096 / TP 8; same tool, custom shapes): the 256x256 tile also wins at 192 and 256
     // tiles (N=1536 K=4096: 84 vs 102 us on the 128x128 kernel; N=2048 K=512: 21 vs 24) and loses when the last round is
     // mostly empty (288 tiles, N=2304 K=4608: 191 vs 180).  So: at least 3/4 of a round, and rounds at least 70 % full.
+    // Round 3, with the separate A / B rings and the persistent tile walk (same tool): the 256x128 form now beats the 128x128 kernel
+    // on the N = h class - M=8192 N=1024: K=4096 57.8-61.5 vs 69.7-70.2 us, K=3072 44.2 vs 50.2-51.1, K=1024 19.2-19.4 vs 21.1-22.4 -
+    // so it takes what the 256x256 tile leaves, under the same fill rule.
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long rounds = (t256 + 255) / 256;
-    return (t256 >= 192 && 10 * t256 >= 7 * 256 * rounds) ? 256 : 0;
+    if (t256 >= 192 && 10 * t256 >= 7 * 256 * rounds) return 256;
+    const long t128 = (long)((M + 255) / 256) * ((N + 127) / 128);
+    const long rounds128 = (t128 + 255) / 256;
+    return (t128 >= 192 && 10 * t128 >= 7 * 256 * rounds128) ? 128 : 0;
 }
 
 int gemm_pp_try(void* C, void* aux, const void* A, const void* B, const void* bias, const void* residual, int M, int N, int K,
