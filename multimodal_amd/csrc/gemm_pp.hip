@@ -161,6 +161,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
         }
     };
 
+    // (Measured and not kept, round 3: the wave's DMA pieces interleaved with its fragment reads - piece, 3 reads, piece, ... - instead
+    // of all pieces, then all reads: 256-wide tiles unchanged (+-0.5 %), 128-wide 4-6 % slower.  Group 1's pieces at the head of its
+    // compute phase, or reads before pieces: 3-8 % slower.  profiles/r03_c_gemm_pp_ab.txt.)
+
     f32x4 acc[4][MI];  // [ni][mi]
     auto compute = [&]() {
         __builtin_amdgcn_sched_barrier(0);
@@ -209,11 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
             compute();
             // A of tile t+1 (issued in phase 2t-1, or in the prologue) has landed: the barrier publishes it to group 1, which reads
             // it in phase 2t+2
-#ifdef MM_AB_PP_T1  // timing only
-            PP_WAIT(P::NPA, 15);
-#else
             PP_WAIT(0, 15);
-#endif
             pp_barrier();                                   // end of phase 2t
             if (t + 1 >= nt) break;                         // nothing left to load: straight to the epilogue (LDS is free:
                                                             // group 1 finished its last fragment reads before this barrier)
@@ -233,11 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
             if (!(DBG & 2) || t == 0) read_frags(t & 1, sbr);
             // fragments in registers, and B of tile t+1 (issued one K-tile ago, or in the prologue) landed - group 0 reads it right
             // after the barrier; the batch just issued stays in flight for two more phases
-#ifdef MM_AB_PP_T2  // timing only
-            PP_WAIT(2 * P::NPB, 0);
-#else
             if (more) PP_WAIT(P::NPB, 0); else PP_WAIT(0, 0);
-#endif
             pp_barrier();                                   // end of phase 2t
             compute();
             if (t + 1 < nt) pp_barrier();                   // end of phase 2t+1
@@ -245,10 +241,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_k(u16* __restrict__ C, u16*
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-#if defined(MM_AB_PP_T1) || defined(MM_AB_PP_T2)
-    PP_WAIT(0, 15);
-    __syncthreads();
-#endif
 
     if (DBG & 4) {  // keep the accumulators alive without storing anything real
         float sum = 0.f;

@@ -16,7 +16,7 @@ for n in ("mm_gemm_nt", "mm_gemm_nt_splitk", "mm_gemm_nt_splitk_workspace_bytes"
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 M = 8192
-for N, K in [(1024, 4096), (1024, 3072), (1024, 2048), (1024, 50304), (2048, 4096)]:
+for N, K in [(1024, 4096), (1024, 3072), (1024, 1024), (1024, 50304), (2048, 4096)]:
     ws_bytes = L.mm_gemm_nt_splitk_workspace_bytes(M, N, K)
     if not ws_bytes:
         print("N=%d K=%d: not a split-K shape in this build" % (N, K))
