@@ -20,6 +20,9 @@ ROWS = [
     ("gemm_nt_pp_k<mm::BF16, 0, false, 256, 0, 1>", "LM head GEMM, ping-pong 256x256", "mfma", 2.0 * T * V * H, ""),
     ("gemm_nt_pp_k<mm::BF16, 0, false, 256, 0, 2>", "LM head data gradient (N = h, K = V), ping-pong 256x256 with in-kernel split-K", "mfma",
      2.0 * T * V * H, "round 3; was on gemm_nt_128_k"),
+    ("gemm_nt_pp_k<mm::BF16, 0, false, 128", "N = h GEMMs (dense, 4h->h, and the dgrads of QKV / dense / h->4h), ping-pong 256x128", "mfma",
+     (24 * 2.0 * T * H * (H + 4 * H + 3 * H + H + 4 * H)) / (24 * 5),
+     "launch-weighted mean of 3 shapes, K = 1024 (x2), 3072, 4096 (x2); round 3, third set: was on gemm_nt_128_k"),
     ("gemm_nt_256_k<mm::BF16, 2, false>", "h->4h GEMM + bias-GeLU (saves pre-activation)", "mfma", 2.0 * T * 4 * H * H, ""),
     ("gemm_nt_256_k<mm::BF16, 6, true>", "4h->h data-gradient GEMM + GeLU'", "mfma", 2.0 * T * 4 * H * H, ""),
     ("gemm_nt_128_k<mm::BF16, 8, false>", "QKV GEMM + bias + rotary", "mfma", 2.0 * T * 3 * H * H, ""),
