@@ -21,6 +21,11 @@
 
 namespace mm {
 
+#ifndef MM_AB_TN_PRE
+#define MM_AB_TN_PRE 4
+#endif
+constexpr int TN_PRE = MM_AB_TN_PRE;  // register sets of tiles in flight (even)
+static_assert(TN_PRE % 2 == 0, "set parity = LDS buffer parity");
 constexpr int TN_BT = 128;  // output tile (rows of C = columns of A) x (cols of C = columns of B)
 
 // stage rows [row0, row0+64) x cols [col0, col0+128) of X (ld elements per row) into a Tile<128> image
@@ -92,26 +97,36 @@ __global__ __launch_bounds__(256) void gemm_tn_k(TnProb p0, TnProb p1, float* __
     const frag ones = Ones<T>::get();
 
     // Tiles come from HBM (dY, X: 16 MiB each) and a 64-token step is only 16 MFMAs per wave, so the loop is bound by how many
-    // bytes are in flight: TWO tiles are prefetched in registers (64 KiB per workgroup) beyond the one being multiplied.
-    // Register set (t & 1) holds tile t from its load until it is written to LDS buffer (t & 1) at the end of iteration t-1.
-    u32x4 areg[2][4], breg[2][4];
-    tn_tile_load(areg[0], A, lda, m_begin, n0, tid);
-    tn_tile_load(breg[0], B, ldb, m_begin, k0, tid);
-    if (ntile > 1) {
-        tn_tile_load(areg[1], A, lda, m_begin + 64, n0, tid);
-        tn_tile_load(breg[1], B, ldb, m_begin + 64, k0, tid);
-    }
+    // bytes are in flight: TN_PRE - 1 tiles are prefetched in registers beyond the one being multiplied (32 KiB each; one
+    // workgroup per CU has the registers for it).  Register set (t % TN_PRE) holds tile t from its load until it is written to
+    // LDS buffer (t & 1) at the end of iteration t-1.
+    u32x4 areg[TN_PRE][4], breg[TN_PRE][4];
+#pragma unroll
+    for (int d = 0; d < TN_PRE; ++d)
+        if (d < ntile) {
+            tn_tile_load(areg[d], A, lda, m_begin + d * 64, n0, tid);
+            tn_tile_load(breg[d], B, ldb, m_begin + d * 64, k0, tid);
+        }
     tile_store<128>(smem, areg[0], tid);
     tile_store<128>(smem + TL::BYTES, breg[0], tid);
     __syncthreads();
 
-    auto body = [&](int t, auto parity) {
-        constexpr int cur = decltype(parity)::value;  // == t & 1
+    // flags: 0 = decide at run time (guards), 1 = always, -1 = never.  The guarded form is only for token counts that are not a
+    // multiple of TN_PRE tiles: behind a conditional load the compiler's s_waitcnt pass no longer knows how many loads are
+    // outstanding and waits for vmcnt(0) before every LDS store (what this kernel did until round 3's third set, with two
+    // register sets).  Measured, tools/ab_tn_pair.py: the straight-line form with four sets and counted waits takes the adapter
+    // pair from 23.8 to 23.2 us - the launch is one round of 256 workgroups whose first fetch, 256 KiB stream and 64 KiB slab
+    // store run one after the other, and the per-step wait was the smallest of the three.
+    auto body = [&](int t, auto phase, auto load_f, auto store_f) {
+        constexpr int set = decltype(phase)::value;  // == t % TN_PRE
+        constexpr int cur = set & 1;                 // == t & 1 (TN_PRE is even)
+        constexpr int nset = (set + 1) % TN_PRE;
+        constexpr int LOAD = decltype(load_f)::value, STORE = decltype(store_f)::value;
         const char* as = smem + cur * 2 * TL::BYTES;
         const char* bs = as + TL::BYTES;
-        if (t + 2 < ntile) {  // set `cur` is free: tile t went to LDS at the end of the previous iteration
-            tn_tile_load(areg[cur], A, lda, m_begin + (t + 2) * 64, n0, tid);
-            tn_tile_load(breg[cur], B, ldb, m_begin + (t + 2) * 64, k0, tid);
+        if (LOAD == 1 || (LOAD == 0 && t + TN_PRE < ntile)) {  // set `set` is free: tile t went to LDS at the end of the previous iteration
+            tn_tile_load(areg[set], A, lda, m_begin + (t + TN_PRE) * 64, n0, tid);
+            tn_tile_load(breg[set], B, ldb, m_begin + (t + TN_PRE) * 64, k0, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -130,16 +145,27 @@ __global__ __launch_bounds__(256) void gemm_tn_k(TnProb p0, TnProb p1, float* __
                 for (int i = 0; i < 2; ++i) cs[i] = M32<T>::run(fa[i], ones, cs[i]);
             }
         }
-        if (t + 1 < ntile) {
+        if (STORE == 1 || (STORE == 0 && t + 1 < ntile)) {
             char* nx = smem + (cur ^ 1) * 2 * TL::BYTES;
-            tile_store<128>(nx, areg[cur ^ 1], tid);
-            tile_store<128>(nx + TL::BYTES, breg[cur ^ 1], tid);
+            tile_store<128>(nx, areg[nset], tid);
+            tile_store<128>(nx + TL::BYTES, breg[nset], tid);
         }
         __syncthreads();
     };
-    for (int t = 0; t < ntile; t += 2) {
-        body(t, std::integral_constant<int, 0>{});
-        if (t + 1 < ntile) body(t + 1, std::integral_constant<int, 1>{});
+    using std::integral_constant;
+    if (ntile % TN_PRE == 0) {
+        // straight-line groups of TN_PRE tiles: every wait in them is a counted vmcnt
+        int t = 0;
+        for (; t + TN_PRE < ntile; t += TN_PRE)
+            static_for<0, TN_PRE>([&](auto d) { body(t + d.value, d, integral_constant<int, 1>{}, integral_constant<int, 1>{}); });
+        static_for<0, TN_PRE>([&](auto d) {
+            body(t + d.value, d, integral_constant<int, -1>{}, integral_constant<int, (d.value + 1 < TN_PRE) ? 1 : -1>{});
+        });
+    } else {
+        for (int t = 0; t < ntile; t += TN_PRE)
+            static_for<0, TN_PRE>([&](auto d) {
+                if (t + d.value < ntile) body(t + d.value, d, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+            });
     }
     // D[row = n (registers)][col = kp (lane)]
     float* wsp = ws + (size_t)by * slab + P.ws_off;
