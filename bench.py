@@ -328,6 +328,16 @@ def main():
         os.environ["MM_BRANCH_STREAMS"] = streams_env
     ops.GEMM_EVENT_PROBE = None
     losses.append(float(loss.detach()))
+    # The same probe once more with the layer's streams AS CONFIGURED (two branch streams by default).  In that form - the one the
+    # timed region replays - the layer gives each branch half the CUs (ops.cu_share), so the h->4h GEMM runs with 128 workgroups
+    # beside the QKV GEMM of the other stream: its own duration is longer than alone on the whole chip, the pair is shorter.
+    probe2 = None
+    if rank == 0 and os.environ.get("MM_BRANCH_STREAMS", "1") != "0":
+        probe2 = {"epilogue": probe["epilogue"], "events": [], "epilogues": {probe["epilogue"]}}
+        ops.GEMM_EVENT_PROBE = probe2
+        with torch.cuda.stream(side):
+            timed(step)
+        ops.GEMM_EVENT_PROBE = None
     dt = dt_graph if dt_graph is not None else dt_plain
 
     tokens_per_step = cfg["micro_batch"] * cfg["seq_length"] * dp_world  # a TP group works on ONE micro-batch
@@ -365,6 +375,17 @@ def main():
             "roofline": roof,
             "roofline_by_time": roofline_by_time(cfg, probe),
         }
+        if probe2 is not None and probe2["events"]:
+            r2 = roofline_from_probe(cfg, probe2, a.tp)
+            share = int(os.environ.get("MM_CU_SHARE", torch.cuda.get_device_properties(device).multi_processor_count // 2))
+            cus = torch.cuda.get_device_properties(device).multi_processor_count
+            out["roofline_in_step"] = {
+                "what": "the same launch as `roofline`, timed in an eager region with the layer's two branch streams: it walks its tiles "
+                        "with %d workgroups (mm_set_cu_share) beside the QKV GEMM on the other stream; `frac` is against the whole "
+                        "chip's peak, `frac_of_share` against the peak of the CUs it occupies" % (share if 0 < share < cus else cus),
+                "workgroups": share if 0 < share < cus else cus, "achieved": r2["achieved"], "peak": r2["peak"], "unit": "TFLOP/s",
+                "frac": r2["frac"], "frac_of_share": round(r2["frac"] * cus / (share if 0 < share < cus else cus), 4),
+                "avg_kernel_ms": r2["avg_kernel_ms"], "launches_timed": r2["launches_timed"]}
         if a.layers:
             out["rehearsal"] = "num_layers overridden to %d: NOT a valid bench number" % a.layers
         if world == 1 and not a.no_cpu_baseline:

@@ -27,6 +27,13 @@ enum { MM_OK = 0, MM_EINVAL = -1, MM_EUNSUPPORTED = -2, MM_ELAUNCH = -3 };
 const char* mm_last_error(void);
 /* Library/arch identification: returns "gfx950". */
 const char* mm_target_arch(void);
+/* Scheduling hint for the calling thread's following launches; returns the previous value.  No counterpart in the reference
+ * (its GEMMs are cuBLAS calls on one stream).  A GPT-J layer runs its attention branch and its MLP GEMMs on two HIP streams
+ * (model/transformer.py); a persistent GEMM that takes every CU serialises the pair.  With max_workgroups = half the CUs
+ * (128 on MI355X) the 256-wide ping-pong kernel (csrc/gemm_pp.hip) walks its tiles with at most that many workgroups when the
+ * problem has more than 256 tiles, so that two such launches on two streams run side by side; 0 (the default) = no limit.
+ * Every other kernel ignores it (measured: the 256x128 form of the N = h class loses).  Results do not depend on it. */
+int mm_set_cu_share(int max_workgroups);
 
 /* ------------------------------------------------------------------ fused softmax
  * Replaces scaled_upper_triang_masked_softmax_cuda.{forward,backward}

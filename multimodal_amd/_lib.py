@@ -22,6 +22,7 @@ c_int, c_float, c_void_p, c_size_t, c_u64 = (
 # (tests/test_abi.py cross-checks this table against the header).
 PROTOTYPES = {
     "mm_last_error": (ctypes.c_char_p, []),
+    "mm_set_cu_share": (ctypes.c_int, [ctypes.c_int]),
     "mm_target_arch": (ctypes.c_char_p, []),
     "mm_softmax_causal_fwd": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "mm_softmax_causal_bwd": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),

@@ -10,6 +10,7 @@
 namespace mm {
 
 void set_error(const char* fmt, ...);
+int cu_share();  // this thread's mm_set_cu_share value (0: none)
 
 #define MM_CHECK_ARG(cond, ...)            \
     do {                                   \

@@ -353,7 +353,15 @@ static int launch_pp(void* C, void* aux, const void* A, const void* B, const voi
     const int nwg = tiles_m * tiles_n;
     int group_m = (nwg / 8) / tiles_n;  // one XCD's run of tiles spans whole tile-rows when it can
     group_m = group_m < 1 ? 1 : (group_m > 8 ? 8 : group_m);
-    dim3 grid(nwg > 256 ? 256 : nwg), block(512);  // persistent: at most one workgroup per CU, each walks its tiles
+    // persistent: at most one workgroup per CU, each walks its tiles.  mm_set_cu_share (include/mm_hip.h): a caller that runs two
+    // of these launches on two streams gives each half the CUs - measured on the 410M step (QKV + rotary beside h->4h + GeLU, GeLU'
+    // data gradient beside the attention backward), same box, alternating: 20.34 -> 19.40 ms.  Alone on 128 CUs the h->4h launch
+    // takes 4 tiles x 25 us instead of 2 x 34.5: with half the CUs in their epilogue at any time the output burst no longer runs
+    // into the HBM write rate (profiles/r03_c_gemm_pp_ab.txt, sections 8-9).  Multiples of 8 keep a workgroup's tiles on one XCD run.
+    int cap = 256;
+    const int share = cu_share() & ~7;
+    if (BN == 256 && nwg > 256 && share >= 8 && share < 256) cap = share;
+    dim3 grid(nwg > cap ? cap : nwg), block(512);
     // (the rotary epilogue carries its tables in the aux / residual slots: never a residual add)
     if (EPI != MM_EPI_BIAS_ROTARY && (epi_is_bwd(EPI) || residual)) {
         if constexpr (EPI != MM_EPI_BIAS_ROTARY)

@@ -5,6 +5,8 @@ Memory policy (MI355X, 288 GB HBM3E): the transposed copy W^T that the data-grad
 K-contiguous operand is cached per FROZEN weight (refreshed when the weight's version counter moves), so a frozen
 language model (reference `freeze_lm`, megatron/training.py:454-459) pays for the transposes once.
 """
+import contextlib
+
 import torch
 
 from . import _lib, _streams, ops
@@ -113,14 +115,16 @@ class MlpFn(torch.autograd.Function):
         out = ops.gemm_nt(act, w2)
         ctx.save_for_backward(x, w1, b1, w2, pre, act)
         ctx.mode = mode
+        ctx.cu_share = ops.current_cu_share() if x.is_cuda else 0  # the layer's two-stream region (model/transformer.py)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, w1, b1, w2, pre, act = ctx.saved_tensors
         dy2 = _flat2d(dy.contiguous())
-        dpre = ops.gemm_nt(dy2, weight_t(w2), b1, _lib.EPI_GELU_TANH_BWD if ctx.mode == 0 else _lib.EPI_GELU_ERF_BWD,
-                           residual=_flat2d(pre))
+        with ops.cu_share(ctx.cu_share) if ctx.cu_share else contextlib.nullcontext():
+            dpre = ops.gemm_nt(dy2, weight_t(w2), b1, _lib.EPI_GELU_TANH_BWD if ctx.mode == 0 else _lib.EPI_GELU_ERF_BWD,
+                               residual=_flat2d(pre))
         dx = dw1 = db1 = dw2 = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dpre, weight_t(w1)).view(x.shape)

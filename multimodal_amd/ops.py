@@ -288,6 +288,30 @@ def gptj_combine(x, attn, attn_bias, mlp, mlp_bias):
 
 
 # ---------------------------------------------------------------------------- GEMM
+class cu_share:
+    """`with ops.cu_share(n):` - scheduling hint for the launches enqueued inside (mm_set_cu_share, include/mm_hip.h): a caller that
+    runs two GEMM chains on two HIP streams gives each n = half the CUs.  Thread-local (the autograd engine runs backward nodes
+    on its own thread: a node re-applies the value it saw in its forward).  n = 0: no limit."""
+
+    def __init__(self, n):
+        self.n = int(n or 0)
+
+    def __enter__(self):
+        self.prev = get_lib().mm_set_cu_share(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        get_lib().mm_set_cu_share(self.prev)
+        return False
+
+
+def current_cu_share():
+    lib = get_lib()
+    v = lib.mm_set_cu_share(0)
+    lib.mm_set_cu_share(v)
+    return v
+
+
 GEMM_SPLITK = True        # plain GEMMs of split-K shapes go to mm_gemm_nt_splitk (False: always mm_gemm_nt; A/B tools flip it)
 GEMM_EVENT_PROBE = None  # set by bench.py to {"epilogues": {codes}, "events": []} to time kernel instantiations in situ
 

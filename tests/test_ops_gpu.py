@@ -444,6 +444,33 @@ def test_gemm_nt_splitk_rejects(ops, cuda_device):
     assert rc != 0   # not a split-K shape: the caller is sent to mm_gemm_nt
 
 
+@pytest.mark.parametrize("share", [128, 96, 8, 100])
+def test_gemm_nt_cu_share_changes_nothing_but_the_grid(ops, cuda_device, share):
+    """mm_set_cu_share is a scheduling hint: the persistent ping-pong kernel walks the same tiles with fewer workgroups
+    (multiples of 8; 100 -> 96) and the result is bit-identical; the previous value comes back when the scope ends."""
+    from multimodal_amd import _lib
+    torch.manual_seed(share)
+    M, N, K = 19 * 256 + 240, 17 * 256 + 128, 320  # 20 x 18 tiles of 256 x 256 (edge tiles in both directions), K not a multiple of 128
+    a = torch.randn(M, K, device=cuda_device).bfloat16()
+    w = (torch.randn(N, K, device=cuda_device) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=cuda_device).bfloat16()
+    assert ops.gemm_nt_kernel_name(M, N, K) == "gemm_nt_pp_k<256>"
+    act0, pre0 = ops.gemm_nt(a, w, bias, _lib.EPI_BIAS_GELU_TANH)
+    plain0 = ops.gemm_nt(a, w)
+    assert ops.current_cu_share() == 0
+    with ops.cu_share(share):
+        assert ops.current_cu_share() == share
+        act1, pre1 = ops.gemm_nt(a, w, bias, _lib.EPI_BIAS_GELU_TANH)
+        plain1 = ops.gemm_nt(a, w)
+        with ops.cu_share(0):
+            assert ops.current_cu_share() == 0
+        assert ops.current_cu_share() == share
+    assert ops.current_cu_share() == 0
+    assert torch.equal(act0, act1) and torch.equal(pre0, pre1) and torch.equal(plain0, plain1)
+    ref = a.float() @ w.float().t()
+    assert ((plain1.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 2e-2).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 8, 48), (1024, 1024, 4), (5, 7, 3), (130, 36, 100)])
 def test_gemm_generic_fallback_ragged_shapes(ops, cuda_device, M, N, K):
     """Shapes the MFMA kernel does not take (K % 64 != 0, N % 4 != 0) run the generic kernel with the same semantics."""

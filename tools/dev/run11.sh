@@ -5,4 +5,4 @@ for r in 1 2; do for v in $VARIANTS; do
 import sys,json
 d=json.loads(sys.stdin.read()); r=d.get('roofline_by_time'); print('$v', d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['avg_kernel_ms'], r['achieved'] if r else None)" || exit 1
 done; done
-cp ab_tmp/libmm_hip_pol.so multimodal_amd/libmm_hip.so
+cp ab_tmp/libmm_hip_cur.so multimodal_amd/libmm_hip.so
