@@ -377,7 +377,7 @@ def main():
         }
         if probe2 is not None and probe2["events"]:
             r2 = roofline_from_probe(cfg, probe2, a.tp)
-            share = int(os.environ.get("MM_CU_SHARE", torch.cuda.get_device_properties(device).multi_processor_count // 2))
+            share = int(os.environ.get("MM_CU_SHARE", str(torch.cuda.get_device_properties(device).multi_processor_count // 2)).split(",")[-1])
             cus = torch.cuda.get_device_properties(device).multi_processor_count
             out["roofline_in_step"] = {
                 "what": "the same launch as `roofline`, timed in an eager region with the layer's two branch streams: it walks its tiles "

@@ -163,15 +163,17 @@ def _side_stream(device):
 _HALF_CUS = {}
 
 
-def _half_cus(device):
-    """Workgroup limit per branch inside the two-stream region: half the CUs (MM_CU_SHARE=<n> overrides, 0 = no limit; A/B)."""
+def _branch_shares(device):
+    """Workgroup limits (attention branch, MLP branch) inside the two-stream region: half the CUs each.
+    MM_CU_SHARE=<n> or <attn>,<mlp> overrides (0 = no limit; A/B)."""
     env = os.environ.get("MM_CU_SHARE")
     if env is not None:
-        return int(env)
+        v = [int(x) for x in env.split(",")]
+        return (v[0], v[-1])
     n = _HALF_CUS.get(device)
     if n is None:
         n = _HALF_CUS[device] = (torch.cuda.get_device_properties(device).multi_processor_count // 2) & ~7
-    return n
+    return (n, n)
 
 
 def _branch_streams():
@@ -254,9 +256,10 @@ class ParallelTransformerLayer(nn.Module):
                     # each branch's big GEMMs take half the CUs, so that the pair runs side by side instead of one persistent
                     # launch after the other (ops.cu_share; step 20.34 -> 19.40 ms on one box)
                     from .. import ops
-                    with ops.cu_share(_half_cus(x2.device)):
-                        with torch.cuda.stream(side):
-                            mlp_raw, mlp_bias = self.mlp.attn_block(x2)
+                    share_attn, share_mlp = _branch_shares(x2.device)
+                    with ops.cu_share(share_mlp), torch.cuda.stream(side):
+                        mlp_raw, mlp_bias = self.mlp.attn_block(x2)
+                    with ops.cu_share(share_attn):
                         attention_output, attention_bias = self.attention(x1, attention_mask, layer_past=layer_past)
                     main.wait_stream(side)
                     x2.record_stream(side)       # allocated on one stream, read on the other: the allocator must not
