@@ -14,6 +14,10 @@ MM_BRANCH_STREAMS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-
 cp /tmp/pk/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 # the profiler prints after the program: the bench line is the last line that STARTS with '{', not the log's last line
 (grep '^{' $OUT/${TAG}_trace.log | tail -1 > $OUT/${TAG}_bench_line.json) || true
+# the same trace with the layer's two branch streams (the form the timed region replays: kernels of the two branches overlap, and
+# inside the region each branch's 256-wide GEMMs run with half the CUs - durations here are NOT a kernel's own time)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk2 -o bench -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace_two_streams.log 2>&1
+cp /tmp/pk2/bench_kernel_stats.csv $OUT/${TAG}_two_stream_kernel_stats.csv
 MM_BRANCH_STREAMS=0 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.log 2>&1
 python3 /root/repo/tools/pmc_by_kernel.py /tmp/pf FETCH_SIZE > $OUT/${TAG}_pmc_fetch_by_kernel.csv
 MM_BRANCH_STREAMS=0 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_write.log 2>&1
