@@ -471,6 +471,26 @@ def test_gemm_nt_cu_share_changes_nothing_but_the_grid(ops, cuda_device, share):
     assert ((plain1.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 2e-2).all()
 
 
+@pytest.mark.parametrize("M,N,K,kernel", [(19 * 256 + 240, 2240, 192, "gemm_nt_pp_k<128>"),     # 20 x 18 tiles of 256 x 128: two per workgroup
+                                           (19 * 256 + 240, 17 * 256 + 128, 128, "gemm_nt_pp_k<256>"),  # two K-tiles only
+                                           (8192, 1024, 1024, "gemm_nt_pp_k<128>")])               # the N = h class: one tile per CU
+def test_gemm_nt_persistent_tile_walk(ops, cuda_device, M, N, K, kernel):
+    """The persistent ping-pong kernel with more tiles than workgroups (next tile's first K-tile fetched before the epilogue, edge
+    tiles in both directions, odd and minimal K-tile counts), against an fp32 product; residual epilogue included."""
+    torch.manual_seed(M + N + K)
+    assert ops.gemm_nt_kernel_name(M, N, K) == kernel
+    a = torch.randn(M, K, device=cuda_device).bfloat16()
+    w = (torch.randn(N, K, device=cuda_device) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device=cuda_device).bfloat16()
+    res = torch.randn(M, N, device=cuda_device).bfloat16()
+    out = ops.gemm_nt(a, w, bias, residual=res)
+    # F.linear's order: fp32 product + bias rounded once, then the residual add rounded
+    ref = ((a.float() @ w.float().t() + bias.float()).bfloat16().float() + res.float()).bfloat16()
+    diff = (out.float() - ref.float()).abs()
+    assert (diff <= 2.0 ** -6 * ref.float().abs() + 2e-2).all()
+    assert (diff == 0).float().mean() > 0.95                         # fp32 summation order is the only difference
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 8, 48), (1024, 1024, 4), (5, 7, 3), (130, 36, 100)])
 def test_gemm_generic_fallback_ragged_shapes(ops, cuda_device, M, N, K):
     """Shapes the MFMA kernel does not take (K % 64 != 0, N % 4 != 0) run the generic kernel with the same semantics."""
